@@ -1,0 +1,161 @@
+"""ctypes binding of the CPU oracle (oracle/orc_api.h).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORC_DIR = ROOT / "oracle"
+
+_libs: dict = {}
+
+
+def _build():
+    need = [ORC_DIR / "liborc_f32.so", ORC_DIR / "liborc_q28.so"]
+    srcs = [ORC_DIR / n for n in ("orc_chain.c", "orc_leaf.c", "orc_types.h", "orc_leaf.h", "orc_common.h", "orc_api.h")]
+    srcs.append(ROOT / "include" / "dspi_detmath.h")
+    newest = max(s.stat().st_mtime for s in srcs)
+    if all(p.exists() and p.stat().st_mtime >= newest for p in need):
+        return
+    subprocess.run(["make", "-C", str(ORC_DIR), "-s"], check=True)
+
+
+def ref_available(flavor: int) -> bool:
+    return (ORC_DIR / "_ref" / f"libref_{'f32' if flavor else 'q28'}.so").exists()
+
+
+def load(flavor: int, ref: bool = False) -> C.CDLL:
+    key = (flavor, ref)
+    if key in _libs:
+        return _libs[key]
+    name = "f32" if flavor else "q28"
+    if ref:
+        path = ORC_DIR / "_ref" / f"libref_{name}.so"
+        if not path.exists() and Path("/root/reference/firmware/DSPi").is_dir():
+            subprocess.run(["make", "-C", str(ORC_DIR), "-s", "ref"], check=True)
+    else:
+        _build()
+        path = ORC_DIR / f"liborc_{name}.so"
+    # RTLD_LOCAL + distinct files: the four builds export identical symbol names
+    lib = C.CDLL(str(path), mode=os.RTLD_LOCAL)
+    lib.orc_new.restype = C.c_void_p
+    lib.orc_free.argtypes = [C.c_void_p]
+    lib.orc_set_sample_rate.argtypes = [C.c_void_p, C.c_uint32]
+    lib.orc_set_host_volume.argtypes = [C.c_void_p, C.c_int16]
+    lib.orc_set_mute.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_factory_defaults.argtypes = [C.c_void_p]
+    lib.orc_load_bulk.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.orc_collect_bulk.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_load_preset_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    lib.orc_save_preset_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.orc_vendor_set.argtypes = [C.c_void_p, C.c_uint8, C.c_uint16, C.c_void_p, C.c_uint16]
+    lib.orc_vendor_get.argtypes = [C.c_void_p, C.c_uint8, C.c_uint16, C.c_void_p, C.c_uint16]
+    lib.orc_get_status.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orc_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_tap.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    lib.orc_tap.restype = C.c_void_p
+    lib.orc_scalar.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_scalar_f.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_scalar_f.restype = C.c_float
+    assert lib.orc_flavor() == flavor and lib.orc_is_ref_build() == int(ref)
+    _libs[key] = lib
+    return lib
+
+
+class Oracle:
+    """One DSPi device (= one stereo stream)."""
+
+    def __init__(self, flavor: int, ref: bool = False, detmath: bool = True, x86_casts: bool = False):
+        self.lib = load(flavor, ref)
+        self.flavor = flavor
+        self.lib.orc_set_math_mode(1 if detmath else 0)
+        self.lib.orc_set_x86_cast_semantics(1 if x86_casts else 0)
+        self.C = self.lib.orc_num_channels()
+        self.N = self.lib.orc_num_outputs()
+        self.P = self.lib.orc_num_pairs()
+        self.h = self.lib.orc_new()
+
+    def close(self):
+        if self.h:
+            self.lib.orc_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_math(self, detmath: bool):
+        self.lib.orc_set_math_mode(1 if detmath else 0)
+
+    def set_rate(self, hz: int) -> int:
+        return self.lib.orc_set_sample_rate(self.h, hz)
+
+    def set_volume(self, v: int):
+        self.lib.orc_set_host_volume(self.h, v)
+
+    def set_mute(self, m: bool):
+        self.lib.orc_set_mute(self.h, int(m))
+
+    def factory_defaults(self):
+        self.lib.orc_factory_defaults(self.h)
+
+    def load_bulk(self, blob) -> int:
+        raw = blob.tobytes() if hasattr(blob, "tobytes") else bytes(blob)
+        return self.lib.orc_load_bulk(self.h, raw, len(raw))
+
+    def collect_bulk(self) -> bytes:
+        buf = C.create_string_buffer(2896)
+        self.lib.orc_collect_bulk(self.h, buf)
+        return buf.raw
+
+    def load_slot(self, image: bytes, expect_slot: int = -1) -> int:
+        return self.lib.orc_load_preset_slot(self.h, image, len(image), expect_slot)
+
+    def save_slot(self, slot_index: int = 0) -> bytes:
+        n = self.lib.orc_preset_slot_size()
+        buf = C.create_string_buffer(n)
+        self.lib.orc_save_preset_slot(self.h, buf, slot_index)
+        return buf.raw
+
+    def vendor_set(self, req: int, wvalue: int, payload: bytes) -> int:
+        return self.lib.orc_vendor_set(self.h, req, wvalue, payload, len(payload))
+
+    def vendor_get(self, req: int, wvalue: int, cap: int = 64):
+        buf = C.create_string_buffer(max(cap, 1))
+        n = self.lib.orc_vendor_get(self.h, req, wvalue, buf, cap)
+        return None if n < 0 else buf.raw[:n]
+
+    def status(self) -> bytes:
+        buf = C.create_string_buffer(self.C * 2 + 4)
+        self.lib.orc_get_status(self.h, buf)
+        return buf.raw
+
+    def tap(self, what: int) -> bytes:
+        n = C.c_int(0)
+        p = self.lib.orc_tap(self.h, what, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def scalar(self, what: int) -> int:
+        return self.lib.orc_scalar(self.h, what)
+
+    def scalar_f(self, what: int) -> float:
+        return self.lib.orc_scalar_f(self.h, what)
+
+    def process(self, pcm: np.ndarray, n_blocks: int, block_len: int, bit_depth: int = 16, want_peaks: bool = True):
+        """pcm: int16 [frames][2] or uint8 [frames*6].  Returns (pairs [P][frames][2], sub [frames], peaks [blocks][C], clip)."""
+        frames = n_blocks * block_len
+        pcm = np.ascontiguousarray(pcm)
+        assert pcm.nbytes == frames * (6 if bit_depth == 24 else 4), (pcm.nbytes, frames)
+        pairs = np.zeros((self.P, frames, 2), dtype=np.int32)
+        sub = np.zeros(frames, dtype=np.int32)
+        peaks = np.zeros((n_blocks, self.C), dtype=np.uint16)
+        clip = np.zeros(1, dtype=np.uint16)
+        self.lib.orc_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, pairs.ctypes.data, sub.ctypes.data,
+                             peaks.ctypes.data if want_peaks else None, clip.ctypes.data)
+        return pairs, sub, peaks, int(clip[0])
