@@ -1,0 +1,400 @@
+// dspi_capi.cpp — the C-ABI of libdspi_mi355x (include/dspi.h): context, device memory, launches.
+//
+// The context owns, per GPU: one state array, one delay-line array and one leveller ring for all
+// streams (laid out per 64-stream workgroup, see dspi_image.h / DESIGN.md), plus a table of
+// parameter images.  Streams reference images; a parameter call addressed to a single stream
+// that shares its image clones the image first (copy-on-write), so "same preset on every
+// stream" stays one broadcast image and per-stream presets still work — each distinct image is
+// one launch over the workgroups (and lane masks) that use it.
+#include <hip/hip_runtime.h>
+
+#include <string.h>
+
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dspi.h"
+#include "dspi_image.h"
+#include "dspi_kernels.h"
+#include "dspi_params.h"
+
+using namespace dspi;
+
+struct dspi_ctx {
+    int flavor = 1;
+    uint32_t n_streams = 0, n_wg = 0;
+    int device = DSPI_DEVICE_NONE;
+    StateMap sm{};
+    std::vector<std::unique_ptr<Params>> images;
+    std::vector<uint32_t> image_refs;
+    std::vector<int32_t> stream_image;
+    bool assignment_dirty = true;
+    std::vector<std::vector<WgItem>> image_items;   // per image: workgroups + lane masks
+    std::vector<uint32_t> image_item_offset;
+    // device
+    hipStream_t hs = nullptr;
+    uint32_t *d_state = nullptr, *d_dlines = nullptr, *d_ring = nullptr;
+    DevImage *d_images = nullptr;
+    size_t d_images_cap = 0;
+    WgItem *d_items = nullptr;
+    size_t d_items_cap = 0;
+    // staging buffers for host-memory dspi_process
+    void *d_in = nullptr; size_t d_in_cap = 0;
+    int32_t *d_pairs = nullptr; size_t d_pairs_cap = 0;
+    int32_t *d_sub = nullptr; size_t d_sub_cap = 0;
+    uint16_t *d_peaks = nullptr; size_t d_peaks_cap = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(dspi_ctx *c, int code, const std::string &msg) { if (c) c->err = msg; return code; }
+
+#define HIPCK(c, call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) return fail((c), DSPI_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+bool valid_stream(const dspi_ctx *c, int32_t s) { return s == DSPI_ALL_STREAMS || (s >= 0 && (uint32_t)s < c->n_streams); }
+
+// parameter object to mutate for `stream` (copy-on-write when shared)
+Params *writable(dspi_ctx *c, int32_t stream) {
+    int32_t idx = c->stream_image[(size_t)stream];
+    if (c->image_refs[(size_t)idx] > 1) {
+        size_t slot = c->images.size();
+        for (size_t i = 0; i < c->images.size(); i++) if (c->image_refs[i] == 0) { slot = i; break; }
+        auto clone = std::make_unique<Params>(*c->images[(size_t)idx]);
+        clone->dirty = true;
+        if (slot == c->images.size()) { c->images.push_back(std::move(clone)); c->image_refs.push_back(0); }
+        else c->images[slot] = std::move(clone);
+        c->image_refs[(size_t)idx]--;
+        c->image_refs[slot] = 1;
+        c->stream_image[(size_t)stream] = (int32_t)slot;
+        c->assignment_dirty = true;
+        idx = (int32_t)slot;
+    }
+    return c->images[(size_t)idx].get();
+}
+
+template <class F>
+int for_targets(dspi_ctx *c, int32_t stream, F f) {
+    if (!c) return DSPI_E_INVAL;
+    if (!valid_stream(c, stream)) return fail(c, DSPI_E_INVAL, "stream index out of range");
+    if (stream == DSPI_ALL_STREAMS) {
+        int rc = 0;
+        for (size_t i = 0; i < c->images.size(); i++)
+            if (c->image_refs[i] > 0) { int r = f(*c->images[i]); if (r != 0) rc = r; }
+        return rc;
+    }
+    return f(*writable(c, stream));
+}
+
+const Params &readable(const dspi_ctx *c, int32_t stream) {
+    return *c->images[(size_t)c->stream_image[stream == DSPI_ALL_STREAMS ? 0 : (size_t)stream]];
+}
+
+template <class P>
+int ensure(dspi_ctx *c, P *&ptr, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (ptr) HIPCK(c, hipFree(ptr));
+    ptr = nullptr; cap = 0;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return fail(c, DSPI_E_NOMEM, "hipMalloc failed (" + std::to_string(bytes) + " bytes)");
+    ptr = (P *)p; cap = bytes;
+    return 0;
+}
+
+int rebuild_assignment(dspi_ctx *c) {
+    const size_t ni = c->images.size();
+    c->image_items.assign(ni, {});
+    std::vector<int32_t> last(ni, -1);
+    for (uint32_t s = 0; s < c->n_streams; s++) {
+        size_t im = (size_t)c->stream_image[s];
+        uint32_t wg = s / kLanes, lane = s % kLanes;
+        auto &v = c->image_items[im];
+        if (last[im] != (int32_t)wg) { v.push_back(WgItem{wg, 0u, 0ull}); last[im] = (int32_t)wg; }
+        v.back().mask |= 1ull << lane;
+    }
+    size_t total = 0;
+    c->image_item_offset.assign(ni, 0);
+    for (size_t i = 0; i < ni; i++) { c->image_item_offset[i] = (uint32_t)total; total += c->image_items[i].size(); }
+    int rc = ensure(c, c->d_items, c->d_items_cap, total * sizeof(WgItem));
+    if (rc) return rc;
+    for (size_t i = 0; i < ni; i++)
+        if (!c->image_items[i].empty())
+            HIPCK(c, hipMemcpyAsync(c->d_items + c->image_item_offset[i], c->image_items[i].data(), c->image_items[i].size() * sizeof(WgItem), hipMemcpyHostToDevice, c->hs));
+    HIPCK(c, hipStreamSynchronize(c->hs));
+    c->assignment_dirty = false;
+    return 0;
+}
+
+bool ops_pending(const StateOps &o) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(&o);
+    for (size_t i = 0; i < sizeof(StateOps) / 4; i++) if (w[i]) return true;
+    return false;
+}
+
+// upload dirty images and run pending state mutations; everything is ordered on c->hs
+int commit_params(dspi_ctx *c) {
+    if (c->assignment_dirty) { int rc = rebuild_assignment(c); if (rc) return rc; }
+    const size_t ni = c->images.size();
+    bool any_dirty = false;
+    for (size_t i = 0; i < ni; i++) if (c->image_refs[i] && c->images[i]->dirty) any_dirty = true;
+    if (any_dirty || ni * sizeof(DevImage) > c->d_images_cap) HIPCK(c, hipStreamSynchronize(c->hs));   // no launch may still be reading an image we overwrite
+    if (ni * sizeof(DevImage) > c->d_images_cap) {
+        DevImage *old = c->d_images; size_t oldcap = c->d_images_cap;
+        c->d_images = nullptr; c->d_images_cap = 0;
+        int rc = ensure(c, c->d_images, c->d_images_cap, (ni + 8) * sizeof(DevImage));
+        if (rc) return rc;
+        if (old) { HIPCK(c, hipMemcpy(c->d_images, old, oldcap, hipMemcpyDeviceToDevice)); HIPCK(c, hipFree(old)); }
+        for (auto &p : c->images) p->dirty = true;
+    }
+    for (size_t i = 0; i < ni; i++) {
+        Params &p = *c->images[i];
+        if (c->image_refs[i] == 0) continue;
+        if (p.dirty) {
+            DevImage img;
+            p.build_image(img);
+            HIPCK(c, hipMemcpy(c->d_images + i, &img, sizeof(img), hipMemcpyHostToDevice));   // synchronous: `img` is a local
+            p.dirty = false;
+        }
+        if (ops_pending(p.ops)) {
+            const auto &items = c->image_items[i];
+            if (!items.empty())
+                HIPCK(c, launch_state_ops(c->flavor, c->d_items + c->image_item_offset[i], (uint32_t)items.size(), p.ops, c->d_state, c->d_dlines,
+                                          c->d_ring, c->n_streams, c->hs));
+            p.ops = StateOps{};
+        }
+    }
+    return 0;
+}
+
+int read_stream_words(dspi_ctx *c, uint32_t stream, int slot0, int count, uint32_t *out) {
+    const uint32_t wg = stream / kLanes, lane = stream % kLanes;
+    const uint32_t *src = c->d_state + ((size_t)wg * c->sm.n_slots + slot0) * kLanes + lane;
+    HIPCK(c, hipStreamSynchronize(c->hs));
+    HIPCK(c, hipMemcpy2D(out, 4, src, kLanes * 4, 4, (size_t)count, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int fetch_status(dspi_ctx *c, int32_t stream, uint16_t *peaks, uint16_t *clip) {
+    for (int i = 0; i < kMaxCh; i++) peaks[i] = 0;
+    *clip = 0;
+    if (c->device == DSPI_DEVICE_NONE) return 0;
+    const uint32_t s = stream == DSPI_ALL_STREAMS ? 0u : (uint32_t)stream;
+    uint32_t w[kMaxCh + 4];
+    int rc = read_stream_words(c, s, c->sm.peaks, c->sm.n_ch + 4, w);
+    if (rc) return rc;
+    for (int i = 0; i < c->sm.n_ch; i++) peaks[i] = (uint16_t)w[i];
+    *clip = (uint16_t)(w[c->sm.n_ch] | w[c->sm.n_ch + 1] | w[c->sm.n_ch + 2] | w[c->sm.n_ch + 3]);
+    return 0;
+}
+
+int zero_clips(dspi_ctx *c, int32_t stream) {
+    if (c->device == DSPI_DEVICE_NONE) return 0;
+    HIPCK(c, hipStreamSynchronize(c->hs));
+    const size_t pitch = (size_t)c->sm.n_slots * kLanes * 4;
+    if (stream == DSPI_ALL_STREAMS) {
+        HIPCK(c, hipMemset2D(c->d_state + (size_t)c->sm.clip * kLanes, pitch, 0, 4 * kLanes * 4, c->n_wg));
+    } else {
+        const uint32_t wg = (uint32_t)stream / kLanes, lane = (uint32_t)stream % kLanes;
+        uint32_t z[4] = {0, 0, 0, 0};
+        HIPCK(c, hipMemcpy2D(c->d_state + ((size_t)wg * c->sm.n_slots + c->sm.clip) * kLanes + lane, kLanes * 4, z, 4, 4, 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dspi_abi_version(void) { return DSPI_ABI_VERSION; }
+
+int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) {
+    if (!out || (flavor != DSPI_FLAVOR_RP2040_Q28 && flavor != DSPI_FLAVOR_RP2350_F32) || n_streams == 0) return DSPI_E_INVAL;
+    dspi_ctx *c = new (std::nothrow) dspi_ctx();
+    if (!c) return DSPI_E_NOMEM;
+    c->flavor = flavor;
+    c->n_streams = n_streams;
+    c->n_wg = (n_streams + kLanes - 1) / kLanes;
+    c->device = hip_device;
+    c->sm = make_state_map(flavor);
+    c->images.push_back(std::make_unique<Params>(flavor));
+    c->image_refs.push_back(n_streams);
+    c->stream_image.assign(n_streams, 0);
+    *out = c;
+    if (hip_device == DSPI_DEVICE_NONE) return DSPI_OK;
+
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { *out = nullptr; delete c; return DSPI_E_NODEVICE; }
+    auto bail = [&](int code) { dspi_destroy(c); *out = nullptr; return code; };
+    if (hipSetDevice(hip_device) != hipSuccess) return bail(DSPI_E_NODEVICE);
+    if (hipStreamCreateWithFlags(&c->hs, hipStreamNonBlocking) != hipSuccess) return bail(DSPI_E_HIP);
+    const size_t state_b = (size_t)c->n_wg * c->sm.n_slots * kLanes * 4;
+    const size_t dl_b = (size_t)c->n_wg * c->sm.n_out * (size_t)c->sm.max_delay * kLanes * 4;
+    const size_t ring_b = (size_t)c->n_wg * kRingLen * 2 * kLanes * 4;
+    if (hipMalloc((void **)&c->d_state, state_b) != hipSuccess || hipMalloc((void **)&c->d_dlines, dl_b) != hipSuccess ||
+        hipMalloc((void **)&c->d_ring, ring_b) != hipSuccess)
+        return bail(DSPI_E_NOMEM);
+    if (hipMemsetAsync(c->d_state, 0, state_b, c->hs) != hipSuccess || hipMemsetAsync(c->d_dlines, 0, dl_b, c->hs) != hipSuccess ||
+        hipMemsetAsync(c->d_ring, 0, ring_b, c->hs) != hipSuccess || launch_state_init(flavor, c->d_state, c->n_wg, c->hs) != hipSuccess ||
+        hipStreamSynchronize(c->hs) != hipSuccess)
+        return bail(DSPI_E_HIP);
+    return DSPI_OK;
+}
+
+void dspi_destroy(dspi_ctx *c) {
+    if (!c) return;
+    if (c->device != DSPI_DEVICE_NONE) {
+        (void)hipSetDevice(c->device);
+        if (c->hs) (void)hipStreamSynchronize(c->hs);
+        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, c->d_in,
+                        (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
+            if (p) (void)hipFree(p);
+        if (c->hs) (void)hipStreamDestroy(c->hs);
+    }
+    delete c;
+}
+
+const char *dspi_last_error(const dspi_ctx *c) { return c ? c->err.c_str() : "null context"; }
+int dspi_num_channels(const dspi_ctx *c) { return c ? c->sm.n_ch : DSPI_E_INVAL; }
+int dspi_num_outputs(const dspi_ctx *c) { return c ? c->sm.n_out : DSPI_E_INVAL; }
+int dspi_num_pairs(const dspi_ctx *c) { return c ? c->sm.n_pairs : DSPI_E_INVAL; }
+uint32_t dspi_num_streams(const dspi_ctx *c) { return c ? c->n_streams : 0; }
+void *dspi_hip_stream(dspi_ctx *c) { return c ? (void *)c->hs : nullptr; }
+
+int dspi_factory_defaults(dspi_ctx *c, int32_t stream) {
+    return for_targets(c, stream, [](Params &p) { p.factory_reset(); return 0; });
+}
+int dspi_load_bulk(dspi_ctx *c, int32_t stream, const void *blob, size_t len) {
+    if (!blob) return DSPI_E_INVAL;
+    return for_targets(c, stream, [&](Params &p) { return p.load_bulk(blob, len); });
+}
+int dspi_collect_bulk(dspi_ctx *c, int32_t stream, void *blob, size_t cap) {
+    if (!c || !blob || !valid_stream(c, stream)) return DSPI_E_INVAL;
+    return readable(c, stream).collect_bulk(blob, cap);
+}
+int dspi_load_preset_slot(dspi_ctx *c, int32_t stream, const void *image, size_t len, int expect_slot) {
+    if (!image) return DSPI_E_INVAL;
+    return for_targets(c, stream, [&](Params &p) { return p.load_slot(image, len, expect_slot); });
+}
+int dspi_save_preset_slot(dspi_ctx *c, int32_t stream, void *image, size_t cap, int slot_index) {
+    if (!c || !image || !valid_stream(c, stream)) return DSPI_E_INVAL;
+    return readable(c, stream).save_slot(image, cap, slot_index);
+}
+int dspi_vendor_set(dspi_ctx *c, int32_t stream, uint8_t req, uint16_t wValue, const void *payload, uint16_t len) {
+    if (len && !payload) return DSPI_E_INVAL;
+    return for_targets(c, stream, [&](Params &p) { return p.vendor_set(req, wValue, payload, len); });
+}
+int dspi_vendor_get(dspi_ctx *c, int32_t stream, uint8_t req, uint16_t wValue, void *buf, uint16_t cap) {
+    if (!c || !buf || !valid_stream(c, stream)) return DSPI_E_INVAL;
+    uint16_t peaks[kMaxCh], clip = 0;
+    const bool needs_status = (req == 0x50 || req == 0x83);
+    if (needs_status) { int rc = fetch_status(c, stream, peaks, &clip); if (rc) return rc; }
+    const uint16_t before = clip;
+    int n;
+    if (req == 0x53) {   // REQ_FACTORY_RESET answers with a status byte and mutates state
+        int rc = dspi_factory_defaults(c, stream);
+        if (rc) return rc;
+        if (cap < 1) return DSPI_E_SHORT;
+        *(uint8_t *)buf = 0;
+        return 1;
+    }
+    if (req == 0xD6) {   // REQ_SAVE_MASTER_VOLUME mutates the directory copy
+        return for_targets(c, stream, [&](Params &p) { int r = p.vendor_get(req, wValue, buf, cap, peaks, &clip); return r < 0 ? r : 0; }) == 0 ? 1 : DSPI_E_SHORT;
+    }
+    Params tmp_view = readable(c, stream);    // GETs never change parameters; work on a copy
+    n = tmp_view.vendor_get(req, wValue, buf, cap, peaks, &clip);
+    if (req == 0x83 && n >= 0 && before != 0) { int rc = zero_clips(c, stream); if (rc) return rc; }
+    return n;
+}
+int dspi_set_host_volume(dspi_ctx *c, int32_t stream, int16_t v) {
+    return for_targets(c, stream, [&](Params &p) { p.set_volume(v); return 0; });
+}
+int dspi_set_mute(dspi_ctx *c, int32_t stream, int mute) {
+    return for_targets(c, stream, [&](Params &p) { p.set_mute(mute != 0); return 0; });
+}
+int dspi_set_sample_rate(dspi_ctx *c, int32_t stream, uint32_t hz) {
+    if (hz != 44100 && hz != 48000 && hz != 96000) return DSPI_E_INVAL;
+    return for_targets(c, stream, [&](Params &p) { return p.set_rate(hz); });
+}
+
+int dspi_get_status(dspi_ctx *c, int32_t stream, void *buf, size_t cap) {
+    if (!c || !buf || !valid_stream(c, stream)) return DSPI_E_INVAL;
+    const int n = c->sm.n_ch * 2 + 4;
+    if (cap < (size_t)n) return DSPI_E_SHORT;
+    return dspi_vendor_get(c, stream, 0x50, 9, buf, (uint16_t)n);
+}
+int dspi_clear_clips(dspi_ctx *c, int32_t stream) {
+    if (!c || !valid_stream(c, stream)) return DSPI_E_INVAL;
+    uint16_t f = 0;
+    int n = dspi_vendor_get(c, stream, 0x83, 0, &f, 2);
+    return n < 0 ? n : (int)f;
+}
+
+int dspi_debug_image(dspi_ctx *c, int32_t stream, void *buf, size_t cap) {
+    if (!c || !buf || !valid_stream(c, stream)) return DSPI_E_INVAL;
+    if (cap < sizeof(DevImage)) return DSPI_E_SHORT;
+    DevImage img;
+    readable(c, stream).build_image(img);
+    memcpy(buf, &img, sizeof(img));
+    return (int)sizeof(img);
+}
+
+int dspi_sync(dspi_ctx *c) {
+    if (!c) return DSPI_E_INVAL;
+    if (c->device == DSPI_DEVICE_NONE) return DSPI_E_NODEVICE;
+    HIPCK(c, hipStreamSynchronize(c->hs));
+    return DSPI_OK;
+}
+
+int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_blocks, uint32_t block_len, const dspi_out *out, uint32_t flags) {
+    if (!c || !pcm_in || !out) return DSPI_E_INVAL;
+    if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
+    if ((bit_depth != 16 && bit_depth != 24) || n_blocks == 0 || block_len == 0 || block_len > DSPI_MAX_BLOCK_LEN)
+        return fail(c, DSPI_E_INVAL, "bit_depth must be 16/24, 1 <= block_len <= 192, n_blocks >= 1");
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = commit_params(c);
+    if (rc) return rc;
+
+    const size_t frames = (size_t)n_blocks * block_len;
+    const size_t in_b = (size_t)c->n_streams * frames * (bit_depth == 24 ? 6 : 4);
+    const size_t pairs_b = (size_t)c->n_streams * c->sm.n_pairs * frames * 8;
+    const size_t sub_b = (size_t)c->n_streams * frames * 4;
+    const size_t peaks_b = (size_t)c->n_streams * n_blocks * c->sm.n_ch * 2;
+    const bool dev = flags & DSPI_MEM_DEVICE;
+
+    KArgs a{};
+    a.state = c->d_state; a.dlines = c->d_dlines; a.ring = c->d_ring;
+    a.n_streams = c->n_streams; a.n_blocks = n_blocks; a.block_len = block_len; a.bit_depth = (uint32_t)bit_depth;
+    if (dev) {
+        a.pcm = pcm_in; a.pairs = out->pairs; a.sub = out->sub; a.peaks = out->peaks;
+    } else {
+        if ((rc = ensure(c, c->d_in, c->d_in_cap, in_b))) return rc;
+        HIPCK(c, hipMemcpyAsync(c->d_in, pcm_in, in_b, hipMemcpyHostToDevice, c->hs));
+        a.pcm = c->d_in;
+        if (out->pairs) { if ((rc = ensure(c, c->d_pairs, c->d_pairs_cap, pairs_b))) return rc; a.pairs = c->d_pairs; }
+        if (out->sub) { if ((rc = ensure(c, c->d_sub, c->d_sub_cap, sub_b))) return rc; a.sub = c->d_sub; }
+        if (out->peaks) { if ((rc = ensure(c, c->d_peaks, c->d_peaks_cap, peaks_b))) return rc; a.peaks = c->d_peaks; }
+    }
+    for (size_t i = 0; i < c->images.size(); i++) {
+        if (c->image_refs[i] == 0 || c->image_items[i].empty()) continue;
+        a.img = c->d_images + i;
+        a.items = c->d_items + c->image_item_offset[i];
+        hipError_t e = launch_chain(c->flavor, a, (uint32_t)c->image_items[i].size(), c->hs);
+        if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
+        if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));
+    }
+    if (!dev) {
+        if (out->pairs) HIPCK(c, hipMemcpyAsync(out->pairs, c->d_pairs, pairs_b, hipMemcpyDeviceToHost, c->hs));
+        if (out->sub) HIPCK(c, hipMemcpyAsync(out->sub, c->d_sub, sub_b, hipMemcpyDeviceToHost, c->hs));
+        if (out->peaks) HIPCK(c, hipMemcpyAsync(out->peaks, c->d_peaks, peaks_b, hipMemcpyDeviceToHost, c->hs));
+        HIPCK(c, hipStreamSynchronize(c->hs));
+    }
+    return DSPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,31 @@
+// dspi_kernels.h — launch interface between the context (dspi_capi.cpp) and dspi_kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "dspi_image.h"
+
+namespace dspi {
+
+constexpr int kChunk = 16;   // frames per in-kernel chunk (divides the 48- and 96-frame packets)
+
+struct KArgs {
+    const DevImage *img;     // one image: every lane of this launch uses it (scalar loads)
+    const WgItem *items;     // workgroups (and lane masks) that belong to the image
+    uint32_t *state;         // [n_wg][n_slots][64]
+    uint32_t *dlines;        // [n_wg][n_out][max_delay][64]
+    uint32_t *ring;          // [n_wg][kRingLen][2][64]
+    const void *pcm;         // [stream][n_blocks*block_len] frames, 4 or 6 bytes each
+    int32_t *pairs;          // [stream][pair][frames][2] or null
+    int32_t *sub;            // [stream][frames] or null
+    uint16_t *peaks;         // [stream][block][C] or null
+    uint32_t n_streams, n_blocks, block_len, bit_depth;
+};
+
+size_t chain_lds_bytes(int flavor);
+hipError_t launch_chain(int flavor, const KArgs &args, uint32_t n_items, hipStream_t stream);
+hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
+                            uint32_t *ring, uint32_t n_streams, hipStream_t stream);
+hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream);
+
+}  // namespace dspi

@@ -1,0 +1,667 @@
+// dspi_kernels.hip — the DSPi per-sample chain as one fused, persistent gfx950 kernel.
+//
+// Reference path: process_audio_packet, firmware/DSPi/usb_audio.c:560-967 (RP2350 float) and
+// :968-1283 (RP2040 Q28), with its leaf loops in dsp_pipeline.c:281-365, dsp_process_rp2040.S:225-394,
+// leveller.c:148-389, crossfeed.c:132-180.
+//
+// Mapping:
+//   * one lane  = one stream; one 256-thread workgroup = 64 streams x 4 waves
+//   * wave 0    = "master": input convert + preamp, loudness, master L/R EQ, leveller, master
+//                 peaks, crossfeed -> post-crossfeed L/R chunk into LDS
+//     waves 1-3 = "outputs": matrix mix, per-output EQ, gain, delay line, peaks, int24 / Q28 words
+//   * the time loop runs inside the kernel (T-frame chunks, packet semantics kept per block);
+//     filter state stays in LDS for the whole launch, coefficients come from one DevImage through
+//     scalar loads (all lanes of a launch share the image), delay lines / leveller ring are
+//     [position][lane] in HBM so every access is a 256-byte coalesced row
+//   * no MFMA: every stage is a per-stream recurrence.  No contraction, FTZ on (build flags).
+//
+// The leveller is a two-pass-per-packet algorithm (envelope over the whole packet, then a gain
+// ramp over the same packet).  Pass 1 of packet k and pass 2 of packet k-1 are interleaved
+// chunk by chunk through a [1024][2][lane] ring in HBM that doubles as the 480-sample lookahead
+// line, so the master wave never holds more than one chunk in registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dspi_detmath.h"
+#include "dspi_image.h"
+#include "dspi_kernels.h"
+
+namespace dspi {
+
+namespace {
+
+constexpr int T = kChunk;   // frames per chunk
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) U4a { u32x4 v; };
+__device__ __forceinline__ u32x4 ld4(const void *p) { return reinterpret_cast<const U4a *>(p)->v; }
+__device__ __forceinline__ void st4(void *p, u32x4 v) { reinterpret_cast<U4a *>(p)->v = v; }
+
+// The image is never written while a launch is in flight; reading it through the constant address
+// space lets the compiler use scalar loads (s_load_dwordx8 per band) instead of per-lane VMEM loads.
+typedef const __attribute__((address_space(4))) DevImage *ImgPtr;
+typedef const __attribute__((address_space(4))) DevBand *BandPtr;
+__device__ __forceinline__ ImgPtr to_const(const DevImage *p) { return (ImgPtr)(uintptr_t)p; }
+
+__device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// ------------------------------------------------------------------------------------------
+// float EQ band runner: the reference's block loops with the state pair in LDS
+// ------------------------------------------------------------------------------------------
+template <bool TAIL, int NB, bool SHELF_ONLY = false>
+__device__ __forceinline__ void run_bands_f32(float (&x)[T], int n, BandPtr bands, float *__restrict__ st) {
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+        BandPtr bd = bands + b;
+        const uint32_t kind = bd->kind;
+        if (kind == K_BYPASS) continue;
+        float *sp = st + b * 2 * kLanes;
+        float s1 = sp[0], s2 = sp[kLanes];
+        const float c0 = bd->c[0].f, c1 = bd->c[1].f, c2 = bd->c[2].f, c3 = bd->c[3].f, c4 = bd->c[4].f, c5 = bd->c[5].f;
+        if (!SHELF_ONLY && kind == K_BIQUAD) {           // dsp_pipeline.c:347-362
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                float in = x[i];
+                float y = c0 * in + s1;
+                s1 = c1 * in - c3 * y + s2;
+                s2 = c2 * in - c4 * y;
+                x[i] = y;
+            }
+        } else {                          // Cytomic SVF core, dsp_pipeline.c:300-343
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                float in = x[i];
+                float v3 = in - s2;
+                float v1 = c0 * s1 + c1 * v3;
+                float v2 = s2 + c1 * s1 + c2 * v3;
+                s1 = 2.0f * v1 - s1;
+                s2 = 2.0f * v2 - s2;
+                float y;
+                if (!SHELF_ONLY && kind == K_SVF_LP) y = v2;
+                else if (!SHELF_ONLY && kind == K_SVF_HP) y = in + c3 * v1 - v2;
+                else if (!SHELF_ONLY && kind == K_SVF_PK) y = in + c3 * v1;
+                else y = c3 * in + c4 * v1 + c5 * v2;
+                x[i] = y;
+            }
+        }
+        sp[0] = s1;
+        sp[kLanes] = s2;
+    }
+}
+
+// soft-knee upward gain computer, leveller.c:124-139
+__device__ __forceinline__ float gain_computer(float x_db, float thr, float ratio, float knee) {
+    float half = knee * 0.5f;
+    if (x_db > (thr + half)) return 0.0f;
+    if (x_db >= (thr - half)) {
+        float d = thr + half - x_db;
+        return (1.0f - 1.0f / ratio) * d * d / (2.0f * knee);
+    }
+    return (thr - x_db) * (1.0f - 1.0f / ratio);
+}
+
+// per-packet gain decision, leveller.c:174-206 (float) == :304-332 (Q28); libm -> dspi_detmath.h
+__device__ __forceinline__ float leveller_block_gain(ImgPtr img, float &gsm_db, float rms_sq, uint32_t count) {
+    float rms_db = 10.0f * dspi_det_log10f(rms_sq + 1e-30f);
+    float gc;
+    if (rms_db < img->lv_gate_db) gc = 0.0f;
+    else {
+        gc = gain_computer(rms_db, img->lv_threshold_db, img->lv_ratio, img->lv_knee_db);
+        gc += img->lv_makeup_db;
+        if (gc > img->lv_max_gain_db) gc = img->lv_max_gain_db;
+    }
+    float a_s = (gc < gsm_db) ? img->lv_alpha_attack : img->lv_alpha_release;
+    float alpha = dspi_det_powf(a_s, (float)count);
+    gsm_db = alpha * gsm_db + (1.0f - alpha) * gc;
+    return dspi_det_powf(10.0f, gsm_db / 20.0f);
+}
+
+struct Geo {   // loop geometry shared by the four waves
+    uint32_t n_blocks, B, cpb, items, lag, steps;
+};
+
+// ==========================================================================================
+// wave 0 — float flavour
+// ==========================================================================================
+struct MasterF32 {
+    float lpL, lpR, apL, apR;                 // crossfeed state (crossfeed.h:45-52)
+    float env_l, env_r, gsm_db, g_cur, g_prev;  // LevellerState scalars (leveller.h:104-113)
+    uint32_t rp1, rp2;                        // ring bases of the pass-1 / pass-2 packet
+    float p2_gain, p2_step;
+    float pk_l, pk_r;
+    uint32_t clip;
+};
+
+template <bool TAIL>
+__device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g,
+                                                MasterF32 &m, float *__restrict__ lds_state, float *__restrict__ xch_base,
+                                                uint32_t wg, uint32_t lane, uint32_t stream, bool active,
+                                                bool do_p1, uint32_t k1, uint32_t c1, bool do_item, uint32_t kq, uint32_t cq, uint32_t q) {
+    const uint32_t flags = img->flags;
+    const bool lev_on = flags & IF_LEVELLER_ON;
+    float xl[T], xr[T];
+    uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * kLanes + lane;
+
+    if (do_p1) {
+        const int n = TAIL ? (int)min((uint32_t)T, g.B - c1 * T) : T;
+        // ---- PASS 1: input conversion + preamp (usb_audio.c:591-686) ----
+        const size_t frame0 = ((size_t)stream * g.n_blocks + k1) * g.B + (size_t)c1 * T;
+        if (a.bit_depth == 24) {
+            const float gl = (1.0f / 8388608.0f) * img->preamp[0].f, gr = (1.0f / 8388608.0f) * img->preamp[1].f;
+            const uint16_t *p = reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(a.pcm) + frame0 * 6);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                uint32_t w0 = 0, w1 = 0, w2 = 0;
+                if (active) { w0 = p[i * 3]; w1 = p[i * 3 + 1]; w2 = p[i * 3 + 2]; }
+                int32_t l = (int32_t)((w0 | (w1 << 16)) << 8) >> 8;          // bytes 0..2, sign-extended
+                int32_t r = (int32_t)(((w1 >> 8) | (w2 << 8)) << 8) >> 8;    // bytes 3..5
+                xl[i] = (float)l * gl;
+                xr[i] = (float)r * gr;
+            }
+        } else {
+            const float gl = (1.0f / 32768.0f) * img->preamp[0].f, gr = (1.0f / 32768.0f) * img->preamp[1].f;
+            const uint32_t *p = static_cast<const uint32_t *>(a.pcm) + frame0;
+            if (!TAIL) {
+#pragma unroll
+                for (int v = 0; v < T / 4; ++v) {
+                    u32x4 w = {0, 0, 0, 0};
+                    if (active) w = ld4(p + v * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xl[v * 4 + e] = (float)(int32_t)(int16_t)(w[e] & 0xffffu) * gl;
+                        xr[v * 4 + e] = (float)((int32_t)w[e] >> 16) * gr;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (i >= n) break;
+                    uint32_t w = active ? p[i] : 0u;
+                    xl[i] = (float)(int32_t)(int16_t)(w & 0xffffu) * gl;
+                    xr[i] = (float)((int32_t)w >> 16) * gr;
+                }
+            }
+        }
+        // ---- loudness shelves (usb_audio.c:688-718) ----
+        run_bands_f32<TAIL, 2, true>(xl, n, img->loud, lds_state + (sm.loud + 0) * kLanes + lane);
+        run_bands_f32<TAIL, 2, true>(xr, n, img->loud, lds_state + (sm.loud + 4) * kLanes + lane);
+        // ---- PASS 2: master EQ (usb_audio.c:721-728) ----
+        if (!(flags & IF_BYPASS_MASTER_EQ)) {
+            if (!(img->ch_bypassed & 1u)) run_bands_f32<TAIL, kBands>(xl, n, img->eq[0], lds_state + (sm.eq + 0) * kLanes + lane);
+            if (!(img->ch_bypassed & 2u)) run_bands_f32<TAIL, kBands>(xr, n, img->eq[1], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
+        }
+        if (lev_on) {
+            // ---- leveller pass 1: RMS envelopes (leveller.c:155-172), samples parked in the ring ----
+            const float ar = img->lv_alpha_rms, nar = 1.0f - ar;
+            const uint32_t base = m.rp1 + c1 * T;
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                m.env_l = ar * m.env_l + nar * (xl[i] * xl[i]);
+                m.env_r = ar * m.env_r + nar * (xr[i] * xr[i]);
+                if (active) {
+                    uint32_t pos = (base + i) & (kRingLen - 1);
+                    ring[(size_t)pos * 2 * kLanes] = as_u(xl[i]);
+                    ring[(size_t)pos * 2 * kLanes + kLanes] = as_u(xr[i]);
+                }
+            }
+            if (c1 == g.cpb - 1) {   // end of packet: gain decision (leveller.c:168-206)
+                if (m.env_l < 1e-30f) m.env_l = 0.0f;
+                if (m.env_r < 1e-30f) m.env_r = 0.0f;
+                float rms_sq = (m.env_l > m.env_r) ? m.env_l : m.env_r;
+                float gn = leveller_block_gain(img, m.gsm_db, rms_sq, g.B);
+                m.g_prev = m.g_cur;
+                m.g_cur = gn;
+                m.rp1 = (m.rp1 + g.B) & (kRingLen - 1);
+            }
+        }
+    }
+
+    if (!do_item) return;
+    const int nq = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
+
+    if (lev_on) {
+        // ---- leveller pass 2: interpolated gain, lookahead, gain-cap limiter (leveller.c:208-261) ----
+        if (cq == 0) {
+            if (g.B == 1) { m.p2_gain = m.g_cur; m.p2_step = 0.0f; }
+            else { m.p2_step = (m.g_cur - m.g_prev) / (float)(g.B - 1); m.p2_gain = m.g_prev; }
+        }
+        const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
+        const uint32_t base = m.rp2 + cq * T - back;
+        float ol[T], orr[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (TAIL && i >= nq) break;
+            uint32_t pos = (base + i) & (kRingLen - 1);
+            uint32_t ul = 0, ur = 0;
+            if (active) { ul = ring[(size_t)pos * 2 * kLanes]; ur = ring[(size_t)pos * 2 * kLanes + kLanes]; }
+            ol[i] = as_f(ul);
+            orr[i] = as_f(ur);
+        }
+        const float ceil_ = 0.70795f;   // LEVELLER_LIMITER_CEIL
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (TAIL && i >= nq) break;
+            float peak = fabsf(ol[i]), pr = fabsf(orr[i]);
+            if (pr > peak) peak = pr;
+            float gg = m.p2_gain;
+            if (peak > 0.0f && gg > 1.0f) {
+                float mg = ceil_ / peak;
+                if (mg < gg) gg = (mg > 1.0f) ? mg : 1.0f;
+            }
+            xl[i] = ol[i] * gg;
+            xr[i] = orr[i] * gg;
+            m.p2_gain += m.p2_step;
+        }
+        if (cq == g.cpb - 1) m.rp2 = (m.rp2 + g.B) & (kRingLen - 1);
+    }
+
+    // ---- PASS 3: master peaks (pre-crossfeed) + crossfeed (usb_audio.c:741-749, crossfeed.c:132-156) ----
+    if (cq == 0) { m.pk_l = 0.0f; m.pk_r = 0.0f; }
+    const bool xf = flags & IF_CROSSFEED_ON;
+    const float a0 = img->xf_lp_a0.f, b1 = img->xf_lp_b1.f, apa = img->xf_ap_a.f;
+    float *xch = xch_base + (size_t)(q & 1u) * (2 * T * kLanes) + lane;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        if (TAIL && i >= nq) break;
+        float ml = xl[i], mr = xr[i];
+        float al = fabsf(ml); if (al > m.pk_l) m.pk_l = al;
+        float ar = fabsf(mr); if (ar > m.pk_r) m.pk_r = ar;
+        if (xf) {
+            float lpl = a0 * ml + b1 * m.lpL;
+            float lpr = a0 * mr + b1 * m.lpR;
+            m.lpL = lpl; m.lpR = lpr;
+            float apl = apa * lpl + m.apL;
+            m.apL = lpl - apa * apl;
+            float apr = apa * lpr + m.apR;
+            m.apR = lpr - apa * apr;
+            float dl = (ml - lpl) + apr;
+            float dr = (mr - lpr) + apl;
+            ml = dl; mr = dr;
+        }
+        xch[i * kLanes] = ml;
+        xch[(T + i) * kLanes] = mr;
+    }
+    if (cq == g.cpb - 1) {   // usb_audio.c:963-966
+        uint32_t p0 = (uint32_t)(fminf(1.0f, m.pk_l) * 32767.0f), p1 = (uint32_t)(fminf(1.0f, m.pk_r) * 32767.0f);
+        if (m.pk_l > 1.001f) m.clip |= 1u;
+        if (m.pk_r > 1.001f) m.clip |= 2u;
+        if (active) {
+            uint32_t *gs = a.state + (size_t)wg * sm.n_slots * kLanes + lane;
+            gs[(sm.peaks + 0) * kLanes] = p0;
+            gs[(sm.peaks + 1) * kLanes] = p1;
+            if (a.peaks) {
+                uint16_t *pp = a.peaks + ((size_t)stream * g.n_blocks + kq) * sm.n_ch;
+                pp[0] = (uint16_t)p0; pp[1] = (uint16_t)p1;
+            }
+        }
+    }
+}
+
+// ==========================================================================================
+// waves 1..3 — float flavour
+// ==========================================================================================
+struct OutF32 {
+    uint32_t widx;                       // delay_write_idx at the start of the current packet
+    uint32_t loading, counter;           // preset_loading, preset_mute_counter
+    float smooth;                        // preset_mute_smooth_gain
+    float vmm;                           // vol_mul_master of the current packet
+    uint32_t clip;
+};
+
+template <bool TAIL>
+__device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g,
+                                                OutF32 &s, float *__restrict__ lds_state, float *__restrict__ lds_pk, const float *__restrict__ xch_base,
+                                                uint32_t wg, uint32_t lane, uint32_t stream, bool active,
+                                                int o_first, int o_count, uint32_t kq, uint32_t cq, uint32_t q) {
+    const uint32_t flags = img->flags;
+    const int n = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
+    const int N = sm.n_out;
+    if (cq == 0) {
+        // ---- packet scalars: preset-mute envelope (usb_audio.c:466-498) and volumes (:564-571) ----
+        bool act = s.loading != 0;
+        if (act) {
+            if (s.counter > g.B) s.counter -= g.B;
+            else { s.counter = 0; s.loading = 0; }
+        }
+        float target = act ? 0.0f : 1.0f;
+        float step = (float)g.B / (float)img->mute_transition;
+        if (step > 1.0f) step = 1.0f;
+        float gg = s.smooth;
+        if (gg < target) { gg += step; if (gg > target) gg = target; }
+        else if (gg > target) { gg -= step; if (gg < target) gg = target; }
+        s.smooth = gg;
+        float vol_mul = img->vol.f;
+        vol_mul *= gg;
+        s.vmm = vol_mul * img->master.f;
+    }
+    // post-crossfeed L/R chunk
+    float L[T], R[T];
+    const float *xch = xch_base + (size_t)(q & 1u) * (2 * T * kLanes) + lane;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        if (TAIL && i >= n) break;
+        L[i] = xch[i * kLanes];
+        R[i] = xch[(T + i) * kLanes];
+    }
+    const bool sub_active = flags & IF_SUB_ACTIVE;
+    const size_t F = (size_t)g.n_blocks * g.B;
+    const size_t frame0 = (size_t)kq * g.B + (size_t)cq * T;
+    int32_t held[T];   // left words of a pair waiting for the right channel
+#pragma unroll
+    for (int i = 0; i < T; ++i) held[i] = 0;
+
+#pragma unroll 1
+    for (int j = 0; j < o_count; ++j) {
+        const int o = o_first + j;
+        const bool is_sub = (o == N - 1);
+        const bool processed = !is_sub || sub_active;     // EQ-worker mode leaves the sub untouched (usb_audio.c:844-845)
+        const bool enabled = (img->out_enabled >> o) & 1u;
+        const bool muted = (img->out_mute >> o) & 1u;
+        float x[T];
+        // ---- PASS 4: matrix mix (usb_audio.c:753-779) ----
+        const float gl = img->mix[0][o].f, gr = img->mix[1][o].f;
+        if (enabled && gl != 0.0f && gr != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = L[i] * gl + R[i] * gr; }
+        } else if (enabled && gl != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = L[i] * gl; }
+        } else if (enabled && gr != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = R[i] * gr; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T; ++i) x[i] = 0.0f;
+        }
+        if (processed) {
+            // ---- PASS 5: per-output EQ + gain (usb_audio.c:877-895) ----
+            if (enabled) {
+                const int ch = 2 + o;
+                if (!muted && !((img->ch_bypassed >> ch) & 1u))
+                    run_bands_f32<TAIL, kBands>(x, n, img->eq[ch], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
+                float gain = muted ? 0.0f : img->out_gain_lin[o] * s.vmm;
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (TAIL && i >= n) break;
+                    float y = x[i] * gain;               // x*1.0f == x, so the reference's "gain != 1" test is not needed
+                    x[i] = (gain == 0.0f) ? 0.0f : y;    // memset branch
+                }
+            }
+            // ---- PASS 6: delay line (usb_audio.c:898-912); [position][lane] rows in HBM ----
+            const int32_t dly = img->delay_samples[o];
+            if ((flags & IF_ANY_DELAY) && dly > 0) {
+                const uint32_t mask = (uint32_t)sm.max_delay - 1u;
+                uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * kLanes + lane;
+                const uint32_t w0 = s.widx + cq * T;
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (TAIL && i >= n) break;
+                    uint32_t w = (w0 + i) & mask;
+                    if (active) {
+                        line[(size_t)w * kLanes] = as_u(x[i]);
+                        x[i] = as_f(line[(size_t)((w - (uint32_t)dly) & mask) * kLanes]);
+                    }
+                }
+            }
+        }
+        // ---- PASS 7: peaks, output words (usb_audio.c:914-959) ----
+        float *pkp = lds_pk + (2 + o) * kLanes + lane;
+        float pk = (cq == 0) ? 0.0f : *pkp;
+        const bool metered = !is_sub || (sub_active && enabled);
+        if (metered) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; float av = fabsf(x[i]); if (av > pk) pk = av; }
+        }
+        *pkp = pk;
+        if (cq == g.cpb - 1) {
+            uint32_t p16 = metered ? (uint32_t)(fminf(1.0f, pk) * 32767.0f) : 0u;
+            if (metered && pk > 1.001f) s.clip |= 1u << (2 + o);
+            if (active) {
+                a.state[((size_t)wg * sm.n_slots + sm.peaks + 2 + o) * kLanes + lane] = p16;
+                if (a.peaks) a.peaks[((size_t)stream * g.n_blocks + kq) * sm.n_ch + 2 + o] = (uint16_t)p16;
+            }
+        }
+        if (is_sub) {
+            if (a.sub && active) {
+                int32_t *dst = a.sub + (size_t)stream * F + frame0;
+                const bool live = sub_active && enabled;
+                if (!TAIL) {
+#pragma unroll
+                    for (int v = 0; v < T / 4; ++v) {
+                        u32x4 w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = live ? (uint32_t)(int32_t)(x[v * 4 + e] * 268435456.0f) : 0u;
+                        st4(dst + v * 4, w);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < T; ++i) { if (i >= n) break; dst[i] = live ? (int32_t)(x[i] * 268435456.0f) : 0; }
+                }
+            }
+        } else {
+            int32_t wv[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                float d = fmaxf(-1.0f, fminf(1.0f, x[i]));
+                wv[i] = (int32_t)(d * 8388607.0f);
+            }
+            const int pair = o >> 1, side = o & 1;
+            const bool partner_here = side ? (j >= 1) : (j + 1 < o_count && o + 1 < N - 1);
+            if (a.pairs && active) {
+                int32_t *dst = a.pairs + (((size_t)stream * sm.n_pairs + pair) * F + frame0) * 2;
+                if (side == 1 && partner_here) {
+                    if (!TAIL) {
+#pragma unroll
+                        for (int v = 0; v < T / 2; ++v) {
+                            u32x4 w = {(uint32_t)held[2 * v], (uint32_t)wv[2 * v], (uint32_t)held[2 * v + 1], (uint32_t)wv[2 * v + 1]};
+                            st4(dst + v * 4, w);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < T; ++i) { if (i >= n) break; dst[i * 2] = held[i]; dst[i * 2 + 1] = wv[i]; }
+                    }
+                } else if (!(side == 0 && partner_here)) {
+#pragma unroll
+                    for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[i * 2 + side] = wv[i]; }
+                }
+            }
+            if (side == 0) {
+#pragma unroll
+                for (int i = 0; i < T; ++i) held[i] = wv[i];
+            }
+        }
+    }
+    if (cq == g.cpb - 1 && (flags & IF_ANY_DELAY)) s.widx = (s.widx + g.B) & ((uint32_t)sm.max_delay - 1u);
+}
+
+// ==========================================================================================
+// the kernel
+// ==========================================================================================
+template <int FLAVOR, bool TAIL>
+__global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
+    constexpr StateMap sm = make_state_map(FLAVOR);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    float *lds_state = reinterpret_cast<float *>(lds);                      // [lds_slots][64]
+    float *lds_pk = lds_state + sm.lds_slots * kLanes;                      // [n_ch][64]
+    float *xch = lds_pk + sm.n_ch * kLanes;                                 // [2][2][T][64]
+
+    const WgItem item = a.items[blockIdx.x];
+    const uint32_t wg = item.wg;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t stream = wg * kLanes + lane;
+    const bool active = ((item.mask >> lane) & 1ull) && stream < a.n_streams;
+    ImgPtr img = to_const(a.img);
+
+    uint32_t *gs = a.state + (size_t)wg * sm.n_slots * kLanes + lane;
+    for (int s = wave; s < sm.lds_slots; s += 4) lds[s * kLanes + lane] = gs[(size_t)s * kLanes];
+    __syncthreads();
+
+    Geo g;
+    g.n_blocks = a.n_blocks; g.B = a.block_len;
+    g.cpb = (g.B + T - 1) / T;
+    g.items = g.n_blocks * g.cpb;
+    g.lag = (img->flags & IF_LEVELLER_ON) ? g.cpb : 0u;
+    g.steps = g.items + g.lag + 1;
+
+    if (wave == 0) {
+        MasterF32 m;
+        m.lpL = as_f(gs[(sm.xfeed + 0) * kLanes]); m.lpR = as_f(gs[(sm.xfeed + 1) * kLanes]);
+        m.apL = as_f(gs[(sm.xfeed + 2) * kLanes]); m.apR = as_f(gs[(sm.xfeed + 3) * kLanes]);
+        m.env_l = as_f(gs[(sm.lev + 0) * kLanes]); m.env_r = as_f(gs[(sm.lev + 1) * kLanes]);
+        m.gsm_db = as_f(gs[(sm.lev + 2) * kLanes]); m.g_cur = as_f(gs[(sm.lev + 3) * kLanes]); m.g_prev = as_f(gs[(sm.lev + 4) * kLanes]);
+        m.rp1 = m.rp2 = gs[sm.ring_pos * kLanes] & (kRingLen - 1);
+        m.p2_gain = 1.0f; m.p2_step = 0.0f; m.pk_l = m.pk_r = 0.0f;
+        m.clip = gs[(sm.clip + 0) * kLanes];
+        uint32_t k1 = 0, c1 = 0, kq = 0, cq = 0;
+        for (uint32_t st = 0; st < g.steps; ++st) {
+            const bool do_p1 = st < g.items;
+            const bool do_item = st >= g.lag && st < g.items + g.lag;
+            const uint32_t q = st - g.lag;
+            if (do_p1 || do_item) {
+                master_step_f32<TAIL>(a, img, sm, g, m, lds_state, xch, wg, lane, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
+            }
+            if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
+            if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
+            __syncthreads();
+        }
+        if (active) {
+            gs[(sm.xfeed + 0) * kLanes] = as_u(m.lpL); gs[(sm.xfeed + 1) * kLanes] = as_u(m.lpR);
+            gs[(sm.xfeed + 2) * kLanes] = as_u(m.apL); gs[(sm.xfeed + 3) * kLanes] = as_u(m.apR);
+            gs[(sm.lev + 0) * kLanes] = as_u(m.env_l); gs[(sm.lev + 1) * kLanes] = as_u(m.env_r);
+            gs[(sm.lev + 2) * kLanes] = as_u(m.gsm_db); gs[(sm.lev + 3) * kLanes] = as_u(m.g_cur); gs[(sm.lev + 4) * kLanes] = as_u(m.g_prev);
+            gs[sm.ring_pos * kLanes] = m.rp1;
+            gs[(sm.clip + 0) * kLanes] = m.clip;
+        }
+    } else {
+        // outputs split 3/3/3 (float) or 2/2/1 (Q28) over waves 1..3
+        const int per = (sm.n_out + 2) / 3;
+        const int o_first = (wave - 1) * per;
+        int o_count = sm.n_out - o_first;
+        if (o_count > per) o_count = per;
+        if (o_count < 0) o_count = 0;
+        OutF32 s;
+        s.widx = gs[sm.widx * kLanes];
+        s.loading = gs[(sm.mute + 0) * kLanes]; s.counter = gs[(sm.mute + 1) * kLanes]; s.smooth = as_f(gs[(sm.mute + 2) * kLanes]);
+        s.vmm = 0.0f;
+        s.clip = gs[(sm.clip + wave) * kLanes];
+        uint32_t kq = 0, cq = 0;
+        for (uint32_t st = 0; st < g.steps; ++st) {
+            if (st >= g.lag + 1) {
+                const uint32_t q = st - g.lag - 1;
+                output_item_f32<TAIL>(a, img, sm, g, s, lds_state, lds_pk, xch, wg, lane, stream, active, o_first, o_count, kq, cq, q);
+                if (++cq == g.cpb) { cq = 0; ++kq; }
+            }
+            __syncthreads();
+        }
+        if (active) {
+            if (wave == 1) {
+                gs[sm.widx * kLanes] = s.widx;
+                gs[(sm.mute + 0) * kLanes] = s.loading; gs[(sm.mute + 1) * kLanes] = s.counter; gs[(sm.mute + 2) * kLanes] = as_u(s.smooth);
+            }
+            gs[(sm.clip + wave) * kLanes] = s.clip;
+        }
+    }
+    __syncthreads();
+    if (active)
+        for (int s = wave; s < sm.lds_slots; s += 4) gs[(size_t)s * kLanes] = lds[s * kLanes + lane];
+}
+
+// ------------------------------------------------------------------------------------------
+// state maintenance: the per-stream side effects of parameter changes (StateOps)
+// ------------------------------------------------------------------------------------------
+template <int FLAVOR>
+__global__ void state_ops_kernel(const WgItem *items, StateOps ops, uint32_t *state, uint32_t *dlines, uint32_t *ring, uint32_t n_streams) {
+    constexpr StateMap sm = make_state_map(FLAVOR);
+    const WgItem item = items[blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6, parts = blockDim.x >> 6;
+    const uint32_t stream = item.wg * kLanes + lane;
+    if (!(((item.mask >> lane) & 1ull) && stream < n_streams)) return;
+    uint32_t *gs = state + (size_t)item.wg * sm.n_slots * kLanes + lane;
+    if (part == 0) {
+        for (int ch = 0; ch < sm.n_ch; ++ch)
+            for (int b = 0; b < kBands; ++b)
+                if (ops.reset_all_eq || ((ops.reset_band[ch] >> b) & 1u)) {
+                    gs[(size_t)(sm.eq + (ch * kBands + b) * 2) * kLanes] = 0;
+                    gs[(size_t)(sm.eq + (ch * kBands + b) * 2 + 1) * kLanes] = 0;
+                }
+        if (ops.reset_crossfeed) for (int i = 0; i < 4; ++i) gs[(size_t)(sm.xfeed + i) * kLanes] = 0;
+        if (ops.reset_leveller) {   // leveller_reset_state: zero everything, unity gains
+            const uint32_t unity = FLAVOR ? 0x3f800000u : (1u << 28);
+            gs[(size_t)(sm.lev + 0) * kLanes] = 0; gs[(size_t)(sm.lev + 1) * kLanes] = 0; gs[(size_t)(sm.lev + 2) * kLanes] = 0;
+            gs[(size_t)(sm.lev + 3) * kLanes] = unity; gs[(size_t)(sm.lev + 4) * kLanes] = unity;
+            gs[(size_t)sm.ring_pos * kLanes] = 0;
+        }
+        if (ops.mute_start) { gs[(size_t)(sm.mute + 0) * kLanes] = 1; gs[(size_t)(sm.mute + 1) * kLanes] = ops.mute_samples; }
+        if (ops.mute_cancel) gs[(size_t)(sm.mute + 0) * kLanes] = 0;
+        if (ops.clear_clips) for (int i = 0; i < 4; ++i) gs[(size_t)(sm.clip + i) * kLanes] = 0;
+    }
+    if (ops.reset_leveller) {
+        uint32_t *r = ring + (size_t)item.wg * kRingLen * 2 * kLanes + lane;
+        for (uint32_t p = part; p < (uint32_t)kRingLen * 2; p += parts) r[(size_t)p * kLanes] = 0;
+    }
+    if (ops.zero_delay_lines) {
+        uint32_t *d = dlines + (size_t)item.wg * sm.n_out * (size_t)sm.max_delay * kLanes + lane;
+        const uint32_t total = (uint32_t)sm.n_out * (uint32_t)sm.max_delay;
+        for (uint32_t p = part; p < total; p += parts) d[(size_t)p * kLanes] = 0;
+    }
+}
+
+// power-on state of a stream: everything zero except unity leveller gains and mute envelope = 1.0
+template <int FLAVOR>
+__global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
+    constexpr StateMap sm = make_state_map(FLAVOR);
+    const uint32_t wg = blockIdx.x, lane = threadIdx.x;
+    if (wg >= n_wg) return;
+    uint32_t *gs = state + (size_t)wg * sm.n_slots * kLanes + lane;
+    const uint32_t unity = FLAVOR ? 0x3f800000u : (1u << 28);
+    gs[(size_t)(sm.lev + 3) * kLanes] = unity;
+    gs[(size_t)(sm.lev + 4) * kLanes] = unity;
+    gs[(size_t)(sm.mute + 2) * kLanes] = 0x3f800000u;   // preset_mute_smooth_gain = 1.0f (usb_audio.c:457)
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------
+size_t chain_lds_bytes(int flavor) {
+    const StateMap sm = make_state_map(flavor);
+    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T) * kLanes * sizeof(uint32_t);
+}
+
+hipError_t launch_chain(int flavor, const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    if (flavor != 1) return hipErrorNotSupported;   // Q28 kernel: see DESIGN.md (round plan)
+    const size_t lds = chain_lds_bytes(flavor);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<1, true>), dim3(n_items), dim3(256), lds, stream, args);
+    else hipLaunchKernelGGL((chain_kernel<1, false>), dim3(n_items), dim3(256), lds, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
+                            uint32_t *ring, uint32_t n_streams, hipStream_t stream) {
+    if (flavor) hipLaunchKernelGGL(state_ops_kernel<1>, dim3(n_items), dim3(1024), 0, stream, items, ops, state, dlines, ring, n_streams);
+    else hipLaunchKernelGGL(state_ops_kernel<0>, dim3(n_items), dim3(1024), 0, stream, items, ops, state, dlines, ring, n_streams);
+    return hipGetLastError();
+}
+
+hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream) {
+    if (flavor) hipLaunchKernelGGL(state_init_kernel<1>, dim3(n_wg), dim3(kLanes), 0, stream, state, n_wg);
+    else hipLaunchKernelGGL(state_init_kernel<0>, dim3(n_wg), dim3(kLanes), 0, stream, state, n_wg);
+    return hipGetLastError();
+}
+
+}  // namespace dspi

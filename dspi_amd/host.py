@@ -1,0 +1,178 @@
+"""ctypes binding of the C-ABI (include/dspi.h) — the Python mirror of the reference's data interface.
+
+There is no fallback: if ``libdspi_mi355x.so`` is missing this module raises, and a context without a
+GPU (``device=None``) can only exercise the parameter surface — ``process`` fails with DSPI_E_NODEVICE.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libdspi_mi355x.so"
+
+ALL = -1
+MEM_DEVICE = 0x1
+E_NODEVICE = -11
+E_UNSUPPORTED = -14
+
+
+class DspiError(RuntimeError):
+    def __init__(self, code: int, msg: str = ""):
+        super().__init__(f"dspi error {code}: {msg}")
+        self.code = code
+
+
+class _Out(C.Structure):
+    _fields_ = [("pairs", C.c_void_p), ("sub", C.c_void_p), ("peaks", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, u32, u16, u8 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint16, C.c_uint8
+    L.dspi_create.argtypes = [C.POINTER(vp), C.c_int, u32, C.c_int]
+    L.dspi_destroy.argtypes = [vp]
+    L.dspi_last_error.argtypes = [vp]
+    L.dspi_last_error.restype = C.c_char_p
+    for name in ("dspi_num_channels", "dspi_num_outputs", "dspi_num_pairs"):
+        getattr(L, name).argtypes = [vp]
+    L.dspi_num_streams.argtypes = [vp]
+    L.dspi_num_streams.restype = u32
+    L.dspi_factory_defaults.argtypes = [vp, i32]
+    L.dspi_load_bulk.argtypes = [vp, i32, vp, C.c_size_t]
+    L.dspi_collect_bulk.argtypes = [vp, i32, vp, C.c_size_t]
+    L.dspi_load_preset_slot.argtypes = [vp, i32, vp, C.c_size_t, C.c_int]
+    L.dspi_save_preset_slot.argtypes = [vp, i32, vp, C.c_size_t, C.c_int]
+    L.dspi_vendor_set.argtypes = [vp, i32, u8, u16, vp, u16]
+    L.dspi_vendor_get.argtypes = [vp, i32, u8, u16, vp, u16]
+    L.dspi_set_host_volume.argtypes = [vp, i32, C.c_int16]
+    L.dspi_set_mute.argtypes = [vp, i32, C.c_int]
+    L.dspi_set_sample_rate.argtypes = [vp, i32, u32]
+    L.dspi_process.argtypes = [vp, vp, C.c_int, u32, u32, C.POINTER(_Out), u32]
+    L.dspi_sync.argtypes = [vp]
+    L.dspi_hip_stream.argtypes = [vp]
+    L.dspi_hip_stream.restype = vp
+    L.dspi_get_status.argtypes = [vp, i32, vp, C.c_size_t]
+    L.dspi_clear_clips.argtypes = [vp, i32]
+    L.dspi_debug_image.argtypes = [vp, i32, vp, C.c_size_t]
+    _lib = L
+    return L
+
+
+class Dspi:
+    """`n_streams` DSPi devices on one GPU (device=None: host-only, parameter surface only)."""
+
+    def __init__(self, flavor: int, n_streams: int, device: int | None = 0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.dspi_create(C.byref(self.h), flavor, n_streams, -1 if device is None else device)
+        if rc != 0:
+            raise DspiError(rc, "dspi_create")
+        self.flavor, self.n_streams = flavor, n_streams
+        self.C = self.L.dspi_num_channels(self.h)
+        self.N = self.L.dspi_num_outputs(self.h)
+        self.P = self.L.dspi_num_pairs(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dspi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int, what: str) -> int:
+        if rc < 0:
+            raise DspiError(rc, f"{what}: {self.L.dspi_last_error(self.h).decode()}")
+        return rc
+
+    # ---- parameters ----
+    def factory_defaults(self, stream: int = ALL):
+        return self._ck(self.L.dspi_factory_defaults(self.h, stream), "factory_defaults")
+
+    def load_bulk(self, blob, stream: int = ALL) -> int:
+        raw = blob.tobytes() if hasattr(blob, "tobytes") else bytes(blob)
+        return self.L.dspi_load_bulk(self.h, stream, raw, len(raw))      # firmware codes 0,-1..-4 are returned as-is
+
+    def collect_bulk(self, stream: int = 0) -> bytes:
+        buf = C.create_string_buffer(2896)
+        self._ck(self.L.dspi_collect_bulk(self.h, stream, buf, 2896), "collect_bulk")
+        return buf.raw
+
+    def load_slot(self, image: bytes, expect_slot: int = -1, stream: int = ALL) -> int:
+        return self.L.dspi_load_preset_slot(self.h, stream, image, len(image), expect_slot)
+
+    def save_slot(self, slot_index: int = 0, stream: int = 0) -> bytes:
+        buf = C.create_string_buffer(4096)
+        n = self._ck(self.L.dspi_save_preset_slot(self.h, stream, buf, 4096, slot_index), "save_slot")
+        return buf.raw[:n]
+
+    def vendor_set(self, req: int, wvalue: int, payload: bytes, stream: int = ALL) -> int:
+        return self.L.dspi_vendor_set(self.h, stream, req, wvalue, payload, len(payload))
+
+    def vendor_get(self, req: int, wvalue: int, cap: int = 64, stream: int = 0):
+        buf = C.create_string_buffer(max(cap, 1))
+        n = self.L.dspi_vendor_get(self.h, stream, req, wvalue, buf, cap)
+        return None if n < 0 else buf.raw[:n]
+
+    def set_volume(self, v: int, stream: int = ALL):
+        return self._ck(self.L.dspi_set_host_volume(self.h, stream, v), "set_host_volume")
+
+    def set_mute(self, m: bool, stream: int = ALL):
+        return self._ck(self.L.dspi_set_mute(self.h, stream, int(m)), "set_mute")
+
+    def set_rate(self, hz: int, stream: int = ALL) -> int:
+        return self.L.dspi_set_sample_rate(self.h, stream, hz)
+
+    def status(self, stream: int = 0) -> bytes:
+        n = self.C * 2 + 4
+        buf = C.create_string_buffer(n)
+        self._ck(self.L.dspi_get_status(self.h, stream, buf, n), "get_status")
+        return buf.raw
+
+    def clear_clips(self, stream: int = ALL) -> int:
+        return self._ck(self.L.dspi_clear_clips(self.h, stream), "clear_clips")
+
+    def debug_image(self, stream: int = 0) -> bytes:
+        buf = C.create_string_buffer(8192)
+        n = self._ck(self.L.dspi_debug_image(self.h, stream, buf, 8192), "debug_image")
+        return buf.raw[:n]
+
+    # ---- audio ----
+    def process_host(self, pcm: np.ndarray, n_blocks: int, block_len: int, bit_depth: int = 16,
+                     want_pairs=True, want_sub=True, want_peaks=True):
+        """Host-memory convenience path (tests): pcm = int16 [streams][frames][2] or uint8 [streams][frames*6].
+        Returns (pairs [S][P][F][2], sub [S][F], peaks [S][blocks][C])."""
+        S, F = self.n_streams, n_blocks * block_len
+        pcm = np.ascontiguousarray(pcm)
+        assert pcm.nbytes == S * F * (6 if bit_depth == 24 else 4), (pcm.shape, S, F)
+        pairs = np.zeros((S, self.P, F, 2), dtype=np.int32) if want_pairs else None
+        sub = np.zeros((S, F), dtype=np.int32) if want_sub else None
+        peaks = np.zeros((S, n_blocks, self.C), dtype=np.uint16) if want_peaks else None
+        out = _Out(pairs.ctypes.data if want_pairs else None, sub.ctypes.data if want_sub else None, peaks.ctypes.data if want_peaks else None)
+        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), 0), "process")
+        return pairs, sub, peaks
+
+    def process_device(self, pcm_ptr: int, n_blocks: int, block_len: int, bit_depth: int = 16,
+                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0):
+        """Zero-copy path: raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous, see sync()."""
+        out = _Out(pairs_ptr or None, sub_ptr or None, peaks_ptr or None)
+        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE), "process")
+
+    def sync(self):
+        self._ck(self.L.dspi_sync(self.h), "sync")
+
+    def hip_stream(self) -> int:
+        return self.L.dspi_hip_stream(self.h) or 0

@@ -1,0 +1,137 @@
+/*
+ * dspi.h — C-ABI of libdspi_mi355x: the DSPi per-sample DSP chain on AMD Instinct MI355X.
+ *
+ * Drop-in boundary.  The reference firmware exposes no plugin/FFI interface: its chain is the
+ * static function process_audio_packet(const uint8_t *data, uint16_t data_len)
+ * (firmware/DSPi/usb_audio.c:500) reading ~40 file-scope globals that the USB control plane
+ * writes.  What is frozen here is therefore the firmware's DATA interface:
+ *
+ *   audio in        interleaved little-endian stereo PCM, 16-bit or packed 24-bit, in packets
+ *                   of block_len frames                 usb_audio.c:528-530, :591-686, :997-1015
+ *   audio out       per S/PDIF pair int32 L,R words carrying a 24-bit sample; PDM sub as int32 Q28
+ *                                                        usb_audio.c:926-955, :1244-1271
+ *   whole state     WireBulkParams (2896 B, v2..v6)      bulk_params.h:42-205, bulk_params.c:178-377
+ *                   PresetSlot v<=12 (+CRC-32)           flash_storage.c:136-189, :597-742
+ *   parameters      EP0 vendor requests bRequest/wValue/payload
+ *                                                        config.h:111-251, usb_audio.c:1632-2021 (SET), :2241-2688 (GET)
+ *   UAC1 controls   volume (1/256 dB), mute, sample rate usb_audio.c:428-440, :1477-1499
+ *   status          REQ_GET_STATUS wValue 9 byte layout  usb_audio.c:2427-2443
+ *
+ * One context drives `n_streams` independent DSPi devices ("streams") on one GPU.  Every
+ * stream owns its filter state, delay lines and meters; parameters live in images shared by
+ * any number of streams (all streams start on one image = factory defaults).
+ *
+ * Numerics: DSPI_FLAVOR_RP2040_Q28 is bit-exact integer arithmetic; DSPI_FLAVOR_RP2350_F32
+ * is IEEE binary32 with flush-to-zero, no contraction.  Both match oracle/ bit-for-bit
+ * (tests/), the leveller's per-block log10f/powf being defined by include/dspi_detmath.h.
+ *
+ * Threading: a context is single-threaded.  Parameter calls take effect at the next
+ * dspi_process() (= at a packet boundary, as in the firmware's main loop, main.c:826-894).
+ * All functions return 0 / a non-negative count on success or a negative DSPI_E_* code; no
+ * exceptions cross the boundary.
+ */
+#ifndef DSPI_H
+#define DSPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSPI_ABI_VERSION 1
+
+/* flavours: values equal the firmware's platform ids (config.h:269-270) */
+#define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
+#define DSPI_FLAVOR_RP2350_F32 1   /* 11 channels, 9 outputs, float, 4096-sample delay lines   */
+
+#define DSPI_ALL_STREAMS (-1)
+#define DSPI_DEVICE_NONE (-1)      /* host-only context: parameter surface works, dspi_process fails */
+#define DSPI_MAX_BLOCK_LEN 192     /* usb_audio.c:273-276, :588 */
+
+/* error codes */
+#define DSPI_OK 0
+#define DSPI_E_INVAL (-10)         /* bad argument */
+#define DSPI_E_NODEVICE (-11)      /* HIP runtime / GPU unavailable or host-only context */
+#define DSPI_E_NOMEM (-12)
+#define DSPI_E_HIP (-13)           /* a HIP call failed; see dspi_last_error() */
+#define DSPI_E_UNSUPPORTED (-14)   /* vendor request outside the DSP subset (USB stall in the firmware) */
+#define DSPI_E_SHORT (-15)         /* output buffer too small */
+/* dspi_load_bulk returns the firmware's own codes: -1 version, -2 platform, -3 channel counts, -4 length */
+/* dspi_load_preset_slot returns PRESET_OK (0) or PRESET_ERR_CRC (3)  (config.h:262-266) */
+
+/* dspi_process flags */
+#define DSPI_MEM_DEVICE 0x1u       /* pcm_in and every pointer in dspi_out are device pointers (zero-copy) */
+
+typedef struct dspi_ctx dspi_ctx;
+
+/* Output buffers, all optional (NULL = not produced).  Layouts, F = n_blocks*block_len frames:
+ *   pairs      int32 [stream][pair][F][2]   pair p = outputs 2p,2p+1; 24-bit sample per word
+ *   sub        int32 [stream][F]            PDM sub channel, Q28 (zeros when the firmware would push nothing)
+ *   peaks      uint16 [stream][block][C]    per-packet peak meters (global_status.peaks, config.h:455-460)
+ * where C = 11 / 7 channels and pair count = 4 / 2. */
+typedef struct dspi_out {
+    int32_t *pairs;
+    int32_t *sub;
+    uint16_t *peaks;
+} dspi_out;
+
+/* ---- lifecycle ---------------------------------------------------------------------- */
+int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device);
+void dspi_destroy(dspi_ctx *ctx);
+const char *dspi_last_error(const dspi_ctx *ctx);
+int dspi_abi_version(void);
+int dspi_num_channels(const dspi_ctx *ctx);   /* 11 / 7 */
+int dspi_num_outputs(const dspi_ctx *ctx);    /* 9 / 5  */
+int dspi_num_pairs(const dspi_ctx *ctx);      /* 4 / 2  */
+uint32_t dspi_num_streams(const dspi_ctx *ctx);
+
+/* ---- whole-state blobs ---------------------------------------------------------------- */
+/* REQ_FACTORY_RESET / loading an empty preset slot: flash_storage.c:1144-1238, :811-833 */
+int dspi_factory_defaults(dspi_ctx *ctx, int32_t stream);
+/* REQ_SET_ALL_PARAMS: main.c:1126-1162 + bulk_params.c:178-377 */
+int dspi_load_bulk(dspi_ctx *ctx, int32_t stream, const void *blob, size_t len);
+/* REQ_GET_ALL_PARAMS: bulk_params.c:62-172.  Returns 2896. */
+int dspi_collect_bulk(dspi_ctx *ctx, int32_t stream, void *blob, size_t cap);
+/* REQ_PRESET_LOAD of an occupied slot: main.c:926-976, flash_storage.c:750-849.
+ * `expect_slot` = slot number the image must carry (validate_slot), or -1 to accept any. */
+int dspi_load_preset_slot(dspi_ctx *ctx, int32_t stream, const void *image, size_t len, int expect_slot);
+/* collect_live_state: flash_storage.c:464-552.  Returns the image size (2864 / 1840). */
+int dspi_save_preset_slot(dspi_ctx *ctx, int32_t stream, void *image, size_t cap, int slot_index);
+
+/* ---- incremental parameters ------------------------------------------------------------ */
+/* vendor_cmd_packet (usb_audio.c:1632-2021): payloads shorter than the request needs are ignored, as upstream */
+int dspi_vendor_set(dspi_ctx *ctx, int32_t stream, uint8_t bRequest, uint16_t wValue, const void *payload, uint16_t len);
+/* vendor_setup_request_handler IN direction (usb_audio.c:2271-2688).  Returns the byte count. */
+int dspi_vendor_get(dspi_ctx *ctx, int32_t stream, uint8_t bRequest, uint16_t wValue, void *buf, uint16_t cap);
+int dspi_set_host_volume(dspi_ctx *ctx, int32_t stream, int16_t volume_1_256_db);   /* audio_set_volume */
+int dspi_set_mute(dspi_ctx *ctx, int32_t stream, int mute);
+int dspi_set_sample_rate(dspi_ctx *ctx, int32_t stream, uint32_t hz);               /* 44100 / 48000 / 96000 */
+
+/* ---- audio ------------------------------------------------------------------------------ */
+/* Runs n_blocks packets of block_len frames for every stream.
+ * pcm_in: [stream][n_blocks*block_len] frames of interleaved LE stereo; bit_depth 16 (4 B/frame)
+ * or 24 (6 B/frame, packed).  With DSPI_MEM_DEVICE the call is asynchronous on the context's
+ * HIP stream (use dspi_sync); without it buffers are host memory and the call returns when
+ * the outputs are in place. */
+int dspi_process(dspi_ctx *ctx, const void *pcm_in, int bit_depth, uint32_t n_blocks, uint32_t block_len,
+                 const dspi_out *out, uint32_t flags);
+int dspi_sync(dspi_ctx *ctx);
+/* the HIP stream (hipStream_t) the context launches on, for event timing by the caller */
+void *dspi_hip_stream(dspi_ctx *ctx);
+
+/* ---- status ------------------------------------------------------------------------------ */
+/* REQ_GET_STATUS wValue 9: peaks[C] LE u16, cpu0, cpu1 (always 0 here), clip_flags LE u16 = 26 / 18 bytes */
+int dspi_get_status(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
+/* REQ_CLEAR_CLIPS: returns the flags that were set */
+int dspi_clear_clips(dspi_ctx *ctx, int32_t stream);
+
+/* ---- introspection for tests (host-side derived parameter image of a stream) ------------ */
+/* Copies the packed device parameter image; returns its size.  Layout is internal (csrc/dspi_image.h). */
+int dspi_debug_image(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSPI_H */
