@@ -47,8 +47,34 @@ __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(fl
 __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // ------------------------------------------------------------------------------------------
+// One band over one chunk, specialised on the output form so that the sample loop is branch-free
+// straight-line code (the reference specialises the same way: dsp_pipeline.c:298-343).
+template <bool TAIL, uint32_t KIND>
+__device__ __forceinline__ void band_loop_f32(float (&x)[T], int n, float &s1, float &s2, float c0, float c1, float c2, float c3, float c4, float c5) {
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        if (TAIL && i >= n) break;
+        const float in = x[i];
+        if (KIND == K_BIQUAD) {           // dsp_pipeline.c:347-362
+            float y = c0 * in + s1;
+            s1 = c1 * in - c3 * y + s2;
+            s2 = c2 * in - c4 * y;
+            x[i] = y;
+        } else {                          // Cytomic SVF core (s1 = ic1eq, s2 = ic2eq)
+            float v3 = in - s2;
+            float v1 = c0 * s1 + c1 * v3;
+            float v2 = s2 + c1 * s1 + c2 * v3;
+            s1 = 2.0f * v1 - s1;
+            s2 = 2.0f * v2 - s2;
+            if (KIND == K_SVF_LP) x[i] = v2;
+            else if (KIND == K_SVF_HP) x[i] = in + c3 * v1 - v2;
+            else if (KIND == K_SVF_PK) x[i] = in + c3 * v1;
+            else x[i] = c3 * in + c4 * v1 + c5 * v2;
+        }
+    }
+}
+
 // float EQ band runner: the reference's block loops with the state pair in LDS
-// ------------------------------------------------------------------------------------------
 template <bool TAIL, int NB, bool SHELF_ONLY = false>
 __device__ __forceinline__ void run_bands_f32(float (&x)[T], int n, BandPtr bands, float *__restrict__ st) {
 #pragma unroll 1
@@ -59,33 +85,13 @@ __device__ __forceinline__ void run_bands_f32(float (&x)[T], int n, BandPtr band
         float *sp = st + b * 2 * kLanes;
         float s1 = sp[0], s2 = sp[kLanes];
         const float c0 = bd->c[0].f, c1 = bd->c[1].f, c2 = bd->c[2].f, c3 = bd->c[3].f, c4 = bd->c[4].f, c5 = bd->c[5].f;
-        if (!SHELF_ONLY && kind == K_BIQUAD) {           // dsp_pipeline.c:347-362
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                if (TAIL && i >= n) break;
-                float in = x[i];
-                float y = c0 * in + s1;
-                s1 = c1 * in - c3 * y + s2;
-                s2 = c2 * in - c4 * y;
-                x[i] = y;
-            }
-        } else {                          // Cytomic SVF core, dsp_pipeline.c:300-343
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                if (TAIL && i >= n) break;
-                float in = x[i];
-                float v3 = in - s2;
-                float v1 = c0 * s1 + c1 * v3;
-                float v2 = s2 + c1 * s1 + c2 * v3;
-                s1 = 2.0f * v1 - s1;
-                s2 = 2.0f * v2 - s2;
-                float y;
-                if (!SHELF_ONLY && kind == K_SVF_LP) y = v2;
-                else if (!SHELF_ONLY && kind == K_SVF_HP) y = in + c3 * v1 - v2;
-                else if (!SHELF_ONLY && kind == K_SVF_PK) y = in + c3 * v1;
-                else y = c3 * in + c4 * v1 + c5 * v2;
-                x[i] = y;
-            }
+        if (SHELF_ONLY) band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5);
+        else switch (kind) {
+            case K_BIQUAD: band_loop_f32<TAIL, K_BIQUAD>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            case K_SVF_LP: band_loop_f32<TAIL, K_SVF_LP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            case K_SVF_HP: band_loop_f32<TAIL, K_SVF_HP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            case K_SVF_PK: band_loop_f32<TAIL, K_SVF_PK>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            default: band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
         }
         sp[0] = s1;
         sp[kLanes] = s2;
@@ -119,6 +125,15 @@ __device__ __forceinline__ float leveller_block_gain(ImgPtr img, float &gsm_db, 
     return dspi_det_powf(10.0f, gsm_db / 20.0f);
 }
 
+// Workgroup barrier for the chunk hand-off.  The only data exchanged between waves inside the time loop
+// lives in LDS, so the barrier must drain LDS traffic (lgkmcnt) but NOT the HBM stores/loads in flight:
+// __syncthreads() would add `s_waitcnt vmcnt(0)` and serialise every step behind its own write-backs.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct Geo {   // loop geometry shared by the four waves
     uint32_t n_blocks, B, cpb, items, lag, steps;
 };
@@ -133,6 +148,8 @@ struct MasterF32 {
     float p2_gain, p2_step;
     float pk_l, pk_r;
     uint32_t clip;
+    u32x4 pre[T / 4];                         // next chunk's PCM words, fetched one step ahead
+    uint32_t pre_valid;
 };
 
 template <bool TAIL>
@@ -144,6 +161,28 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
     const bool lev_on = flags & IF_LEVELLER_ON;
     float xl[T], xr[T];
     uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * kLanes + lane;
+    const int nq = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
+
+    // Pass-2 operands come out of the ring (written >= one packet ago): issue those loads first so
+    // they are in flight underneath the pass-1 arithmetic below.
+    float ol[T], orr[T];
+    if (lev_on && do_item) {
+        if (cq == 0) {   // latch the ramp of packet kq before pass 1 below can decide the next packet's gain
+            if (g.B == 1) { m.p2_gain = m.g_cur; m.p2_step = 0.0f; }
+            else { m.p2_step = (m.g_cur - m.g_prev) / (float)(g.B - 1); m.p2_gain = m.g_prev; }
+        }
+        const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
+        const uint32_t base = m.rp2 + cq * T - back;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (TAIL && i >= nq) break;
+            uint32_t pos = (base + i) & (kRingLen - 1);
+            uint32_t ul = 0, ur = 0;
+            if (active) { ul = ring[(size_t)pos * 2 * kLanes]; ur = ring[(size_t)pos * 2 * kLanes + kLanes]; }
+            ol[i] = as_f(ul);
+            orr[i] = as_f(ur);
+        }
+    }
 
     if (do_p1) {
         const int n = TAIL ? (int)min((uint32_t)T, g.B - c1 * T) : T;
@@ -166,15 +205,25 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
             const float gl = (1.0f / 32768.0f) * img->preamp[0].f, gr = (1.0f / 32768.0f) * img->preamp[1].f;
             const uint32_t *p = static_cast<const uint32_t *>(a.pcm) + frame0;
             if (!TAIL) {
+                if (!m.pre_valid) {
+#pragma unroll
+                    for (int v = 0; v < T / 4; ++v) { m.pre[v] = u32x4{0, 0, 0, 0}; if (active) m.pre[v] = ld4(p + v * 4); }
+                }
 #pragma unroll
                 for (int v = 0; v < T / 4; ++v) {
-                    u32x4 w = {0, 0, 0, 0};
-                    if (active) w = ld4(p + v * 4);
+                    const u32x4 w = m.pre[v];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         xl[v * 4 + e] = (float)(int32_t)(int16_t)(w[e] & 0xffffu) * gl;
                         xr[v * 4 + e] = (float)((int32_t)w[e] >> 16) * gr;
                     }
+                }
+                // fetch the next chunk now; it lands while this one goes through loudness + EQ
+                const bool more = (c1 + 1 < g.cpb) || (k1 + 1 < g.n_blocks);
+                m.pre_valid = more;
+                if (more && active) {
+#pragma unroll
+                    for (int v = 0; v < T / 4; ++v) m.pre[v] = ld4(p + T + v * 4);   // chunks of one stream are contiguous across packets
                 }
             } else {
 #pragma unroll
@@ -222,26 +271,9 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
     }
 
     if (!do_item) return;
-    const int nq = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
 
     if (lev_on) {
         // ---- leveller pass 2: interpolated gain, lookahead, gain-cap limiter (leveller.c:208-261) ----
-        if (cq == 0) {
-            if (g.B == 1) { m.p2_gain = m.g_cur; m.p2_step = 0.0f; }
-            else { m.p2_step = (m.g_cur - m.g_prev) / (float)(g.B - 1); m.p2_gain = m.g_prev; }
-        }
-        const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
-        const uint32_t base = m.rp2 + cq * T - back;
-        float ol[T], orr[T];
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            if (TAIL && i >= nq) break;
-            uint32_t pos = (base + i) & (kRingLen - 1);
-            uint32_t ul = 0, ur = 0;
-            if (active) { ul = ring[(size_t)pos * 2 * kLanes]; ur = ring[(size_t)pos * 2 * kLanes + kLanes]; }
-            ol[i] = as_f(ul);
-            orr[i] = as_f(ur);
-        }
         const float ceil_ = 0.70795f;   // LEVELLER_LIMITER_CEIL
 #pragma unroll
         for (int i = 0; i < T; ++i) {
@@ -363,6 +395,26 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
         const bool enabled = (img->out_enabled >> o) & 1u;
         const bool muted = (img->out_mute >> o) & 1u;
         float x[T];
+        // Delay line: the packet's read positions were written >= T samples ago unless the delay is
+        // shorter than a chunk (or aliases to zero at dly == max_delay, config.h:83-88), so the reads can
+        // be issued up front and land underneath the EQ arithmetic.
+        const int32_t dly = img->delay_samples[o];
+        const bool dl_on = processed && (flags & IF_ANY_DELAY) && dly > 0;
+        const bool dl_alias = dl_on && dly >= sm.max_delay;          // reads back what it just wrote
+        const bool dl_early = dl_on && !dl_alias && dly >= T;
+        const uint32_t dmask = (uint32_t)sm.max_delay - 1u;
+        uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * kLanes + lane;
+        const uint32_t w0 = s.widx + cq * T;
+        float dl[T];
+        if (dl_early) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                uint32_t u = 0;
+                if (active) u = line[(size_t)((w0 + i - (uint32_t)dly) & dmask) * kLanes];
+                dl[i] = as_f(u);
+            }
+        }
         // ---- PASS 4: matrix mix (usb_audio.c:753-779) ----
         const float gl = img->mix[0][o].f, gr = img->mix[1][o].f;
         if (enabled && gl != 0.0f && gr != 0.0f) {
@@ -393,18 +445,21 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
                 }
             }
             // ---- PASS 6: delay line (usb_audio.c:898-912); [position][lane] rows in HBM ----
-            const int32_t dly = img->delay_samples[o];
-            if ((flags & IF_ANY_DELAY) && dly > 0) {
-                const uint32_t mask = (uint32_t)sm.max_delay - 1u;
-                uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * kLanes + lane;
-                const uint32_t w0 = s.widx + cq * T;
+            if (dl_early || dl_alias) {
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
                     if (TAIL && i >= n) break;
-                    uint32_t w = (w0 + i) & mask;
+                    if (active) line[(size_t)((w0 + i) & dmask) * kLanes] = as_u(x[i]);
+                    if (dl_early) x[i] = dl[i];
+                }
+            } else if (dl_on) {      // delay shorter than a chunk: the reference's per-sample order
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (TAIL && i >= n) break;
+                    uint32_t w = (w0 + i) & dmask;
                     if (active) {
                         line[(size_t)w * kLanes] = as_u(x[i]);
-                        x[i] = as_f(line[(size_t)((w - (uint32_t)dly) & mask) * kLanes]);
+                        x[i] = as_f(line[(size_t)((w - (uint32_t)dly) & dmask) * kLanes]);
                     }
                 }
             }
@@ -518,6 +573,9 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         m.gsm_db = as_f(gs[(sm.lev + 2) * kLanes]); m.g_cur = as_f(gs[(sm.lev + 3) * kLanes]); m.g_prev = as_f(gs[(sm.lev + 4) * kLanes]);
         m.rp1 = m.rp2 = gs[sm.ring_pos * kLanes] & (kRingLen - 1);
         m.p2_gain = 1.0f; m.p2_step = 0.0f; m.pk_l = m.pk_r = 0.0f;
+        m.pre_valid = 0;
+#pragma unroll
+        for (int v = 0; v < T / 4; ++v) m.pre[v] = u32x4{0, 0, 0, 0};
         m.clip = gs[(sm.clip + 0) * kLanes];
         uint32_t k1 = 0, c1 = 0, kq = 0, cq = 0;
         for (uint32_t st = 0; st < g.steps; ++st) {
@@ -529,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             }
             if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
             if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
-            __syncthreads();
+            lds_barrier();
         }
         if (active) {
             gs[(sm.xfeed + 0) * kLanes] = as_u(m.lpL); gs[(sm.xfeed + 1) * kLanes] = as_u(m.lpR);
@@ -558,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
                 output_item_f32<TAIL>(a, img, sm, g, s, lds_state, lds_pk, xch, wg, lane, stream, active, o_first, o_count, kq, cq, q);
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
-            __syncthreads();
+            lds_barrier();
         }
         if (active) {
             if (wave == 1) {

@@ -1,0 +1,48 @@
+"""Ablation timing of the chain kernel on the bench workload (development aid): which stage costs what."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from dspi_amd import wire as W, workloads as WL
+from dspi_amd.host import Dspi
+
+S = int(os.environ.get('S', 65536)); NB = 25; B = 96; FS = 96000
+dev = torch.device('cuda', 0)
+pcm = torch.randint(-16384, 16385, (S, NB * B, 2), dtype=torch.int16, device=dev)
+pairs = torch.empty((S, 4, NB * B, 2), dtype=torch.int32, device=dev)
+sub = torch.empty((S, NB * B), dtype=torch.int32, device=dev)
+peaks = torch.empty((S, NB, 11), dtype=torch.int16, device=dev)
+
+
+def run(label, blob, outputs=True, steps=4):
+    d = Dspi(1, S, device=0)
+    d.set_rate(FS); d.set_volume(-20 * 256)
+    assert d.load_bulk(blob) == 0
+    args = (pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr()) if outputs else (0, 0, 0)
+    d.process_device(pcm.data_ptr(), NB, B, 16, *args); d.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d.process_device(pcm.data_ptr(), NB, B, 16, *args)
+    d.sync()
+    dt = (time.perf_counter() - t0) / steps
+    print(f'{label:44s} {dt * 1e3:8.2f} ms/step  {S * NB * B / dt / 1e9:7.2f} Gframes/s', flush=True)
+    d.close()
+
+
+full = WL.full_chain_blob(1)
+run('full chain', full)
+run('full chain, no output buffers', full, outputs=False)
+b = full.copy(); b['outputs']['delay_ms'] = 0.0
+run('no user delays (sub align only)', b)
+b = full.copy(); b['leveller']['enabled'] = 0
+run('leveller off', b)
+b = full.copy(); b['leveller']['enabled'] = 0; b['outputs']['delay_ms'] = 0.0
+run('leveller off + no delays', b)
+run('leveller off + no delays + no outputs', b, outputs=False)
+b2 = b.copy(); b2['eq']['type'][2:] = 0
+run('  ... + output EQ flat', b2, outputs=False)
+b3 = b2.copy(); b3['eq']['type'][:] = 0; b3['global_']['loudness_enabled'] = 0; b3['crossfeed']['enabled'] = 0
+run('  ... + everything flat (I/O skeleton only)', b3, outputs=False)
+run('everything flat, with outputs', b3)
+b4 = full.copy(); b4['outputs']['enabled'][2:] = 0
+run('full chain, only outputs 0-1 enabled', b4)
