@@ -17,7 +17,7 @@
 //
 // The leveller is a two-pass-per-packet algorithm (envelope over the whole packet, then a gain
 // ramp over the same packet).  Pass 1 of packet k and pass 2 of packet k-1 are interleaved
-// chunk by chunk through a [1024][2][lane] ring in HBM that doubles as the 480-sample lookahead
+// chunk by chunk through a [2][1024][lane] ring in HBM that doubles as the 480-sample lookahead
 // line, so the master wave never holds more than one chunk in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,6 +45,8 @@ __device__ __forceinline__ ImgPtr to_const(const DevImage *p) { return (ImgPtr)(
 
 __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+#include "dspi_bandloops.inc"
 
 // ------------------------------------------------------------------------------------------
 // One band over one chunk, specialised on the output form so that the sample loop is branch-free
@@ -74,28 +76,72 @@ __device__ __forceinline__ void band_loop_f32(float (&x)[T], int n, float &s1, f
     }
 }
 
-// float EQ band runner: the reference's block loops with the state pair in LDS
+// float EQ band runner: the reference's block loops with the state pair in LDS.  Software-pipelined by
+// hand: the coefficients (scalar loads) and state pair (LDS) of band b+1 are requested before band b's
+// sample loop starts, so their latency hides under ~200 VALU instructions instead of stalling every band.
 template <bool TAIL, int NB, bool SHELF_ONLY = false>
 __device__ __forceinline__ void run_bands_f32(float (&x)[T], int n, BandPtr bands, float *__restrict__ st) {
+    uint32_t kind = bands[0].kind;
+    float c0 = bands[0].c[0].f, c1 = bands[0].c[1].f, c2 = bands[0].c[2].f, c3 = bands[0].c[3].f, c4 = bands[0].c[4].f, c5 = bands[0].c[5].f;
+    float s1 = st[0], s2 = st[kLanes];
+    // Make band 0's operands "used" before the loop: otherwise the wait for them is placed inside the loop
+    // body, after the prefetch of band b+1 has been issued, and (SMEM returning out of order) drains that too.
+    asm volatile("" ::"s"(kind), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "v"(s1), "v"(s2));
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
-        BandPtr bd = bands + b;
-        const uint32_t kind = bd->kind;
-        if (kind == K_BYPASS) continue;
-        float *sp = st + b * 2 * kLanes;
-        float s1 = sp[0], s2 = sp[kLanes];
-        const float c0 = bd->c[0].f, c1 = bd->c[1].f, c2 = bd->c[2].f, c3 = bd->c[3].f, c4 = bd->c[4].f, c5 = bd->c[5].f;
-        if (SHELF_ONLY) band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5);
-        else switch (kind) {
-            case K_BIQUAD: band_loop_f32<TAIL, K_BIQUAD>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-            case K_SVF_LP: band_loop_f32<TAIL, K_SVF_LP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-            case K_SVF_HP: band_loop_f32<TAIL, K_SVF_HP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-            case K_SVF_PK: band_loop_f32<TAIL, K_SVF_PK>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-            default: band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+        uint32_t nkind = K_BYPASS;
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f, n4 = 0.f, n5 = 0.f, ns1 = 0.f, ns2 = 0.f;
+        if (b + 1 < NB) {
+            BandPtr nb = bands + b + 1;
+            nkind = nb->kind;
+            n0 = nb->c[0].f; n1 = nb->c[1].f; n2 = nb->c[2].f; n3 = nb->c[3].f; n4 = nb->c[4].f; n5 = nb->c[5].f;
+            ns1 = st[(b + 1) * 2 * kLanes];
+            ns2 = st[(b + 1) * 2 * kLanes + kLanes];
         }
-        sp[0] = s1;
-        sp[kLanes] = s2;
+        if (kind != K_BYPASS) {
+            if (SHELF_ONLY) band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5);
+            else switch (kind) {
+                case K_BIQUAD: band_loop_f32<TAIL, K_BIQUAD>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_LP: band_loop_f32<TAIL, K_SVF_LP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_HP: band_loop_f32<TAIL, K_SVF_HP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_PK: band_loop_f32<TAIL, K_SVF_PK>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                default: band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            }
+            st[b * 2 * kLanes] = s1;
+            st[b * 2 * kLanes + kLanes] = s2;
+        }
+        kind = nkind; c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5; s1 = ns1; s2 = ns2;
     }
+}
+
+// Full-chunk runner on the hand-scheduled loops of dspi_bandloops.inc.  The kind dispatch happens inside the asm
+// statement, so from the compiler's point of view every band is one in-place update of x[0..15]: no copies.
+template <int NB, bool SHELF_ONLY>
+__device__ __forceinline__ void run_bands16(float (&x)[T], BandPtr bands, float *__restrict__ st) {
+    uint32_t kind = bands[0].kind;
+    float c0 = bands[0].c[0].f, c1 = bands[0].c[1].f, c2 = bands[0].c[2].f, c3 = bands[0].c[3].f, c4 = bands[0].c[4].f, c5 = bands[0].c[5].f;
+    float s1 = st[0], s2 = st[kLanes];
+    asm volatile("" ::"s"(kind), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "v"(s1), "v"(s2));   // see run_bands_f32
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+        // prefetch band b+1 (the last iteration harmlessly re-reads band NB-1: no control flow, nothing to peel)
+        const int bn = (b + 1 < NB) ? b + 1 : b;
+        BandPtr nb = bands + bn;
+        const uint32_t nkind = nb->kind;
+        const float n0 = nb->c[0].f, n1 = nb->c[1].f, n2 = nb->c[2].f, n3 = nb->c[3].f, n4 = nb->c[4].f, n5 = nb->c[5].f;
+        const float ns1 = st[bn * 2 * kLanes], ns2 = st[bn * 2 * kLanes + kLanes];
+        if (SHELF_ONLY) band16_shelf(x, s1, s2, kind, c0, c1, c2, c3, c4, c5);
+        else band16_any(x, s1, s2, kind, c0, c1, c2, c3, c4, c5);
+        st[b * 2 * kLanes] = s1;             // unconditional: a bypassed band writes back what it read
+        st[b * 2 * kLanes + kLanes] = s2;
+        kind = nkind; c0 = n0; c1 = n1; c2 = n2; c3 = n3; c4 = n4; c5 = n5; s1 = ns1; s2 = ns2;
+    }
+}
+
+template <bool TAIL, int NB, bool SHELF_ONLY = false>
+__device__ __forceinline__ void run_bands(float (&x)[T], int n, BandPtr bands, float *__restrict__ st) {
+    if (TAIL) run_bands_f32<true, NB, SHELF_ONLY>(x, n, bands, st);
+    else run_bands16<NB, SHELF_ONLY>(x, bands, st);
 }
 
 // soft-knee upward gain computer, leveller.c:124-139
@@ -133,6 +179,20 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+
+#ifdef DSPI_WAVE_TIMING
+// development aid: per-wave busy cycles (outside the barrier) and total cycles, summed over workgroups
+__device__ unsigned long long g_wave_timing[8];
+#define WT_DECL unsigned long long wt_busy = 0, wt_t0 = __builtin_amdgcn_s_memtime(), wt_start = wt_t0
+#define WT_BEFORE_BARRIER wt_busy += __builtin_amdgcn_s_memtime() - wt_t0
+#define WT_AFTER_BARRIER wt_t0 = __builtin_amdgcn_s_memtime()
+#define WT_FINISH(w) do { if (lane == 0) { atomicAdd(&g_wave_timing[(w) * 2], wt_busy); atomicAdd(&g_wave_timing[(w) * 2 + 1], __builtin_amdgcn_s_memtime() - wt_start); } } while (0)
+#else
+#define WT_DECL
+#define WT_BEFORE_BARRIER
+#define WT_AFTER_BARRIER
+#define WT_FINISH(w)
+#endif
 
 struct Geo {   // loop geometry shared by the four waves
     uint32_t n_blocks, B, cpb, items, lag, steps;
@@ -172,15 +232,27 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
             else { m.p2_step = (m.g_cur - m.g_prev) / (float)(g.B - 1); m.p2_gain = m.g_prev; }
         }
         const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
-        const uint32_t base = m.rp2 + cq * T - back;
+        const uint32_t base = (m.rp2 + cq * T - back) & (kRingLen - 1);
+        if (__all(base + T <= (uint32_t)kRingLen)) {          // no wrap inside the chunk: one base + immediate offsets
+            const uint32_t *rl = ring + (size_t)base * kLanes;
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-            if (TAIL && i >= nq) break;
-            uint32_t pos = (base + i) & (kRingLen - 1);
-            uint32_t ul = 0, ur = 0;
-            if (active) { ul = ring[(size_t)pos * 2 * kLanes]; ur = ring[(size_t)pos * 2 * kLanes + kLanes]; }
-            ol[i] = as_f(ul);
-            orr[i] = as_f(ur);
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= nq) break;
+                uint32_t ul = 0, ur = 0;
+                if (active) { ul = rl[i * kLanes]; ur = rl[(kRingLen + i) * kLanes]; }
+                ol[i] = as_f(ul);
+                orr[i] = as_f(ur);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= nq) break;
+                uint32_t pos = (base + i) & (kRingLen - 1);
+                uint32_t ul = 0, ur = 0;
+                if (active) { ul = ring[(size_t)pos * kLanes]; ur = ring[(size_t)(kRingLen + pos) * kLanes]; }
+                ol[i] = as_f(ul);
+                orr[i] = as_f(ur);
+            }
         }
     }
 
@@ -236,26 +308,31 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
             }
         }
         // ---- loudness shelves (usb_audio.c:688-718) ----
-        run_bands_f32<TAIL, 2, true>(xl, n, img->loud, lds_state + (sm.loud + 0) * kLanes + lane);
-        run_bands_f32<TAIL, 2, true>(xr, n, img->loud, lds_state + (sm.loud + 4) * kLanes + lane);
+        run_bands<TAIL, 2, true>(xl, n, img->loud, lds_state + (sm.loud + 0) * kLanes + lane);
+        run_bands<TAIL, 2, true>(xr, n, img->loud, lds_state + (sm.loud + 4) * kLanes + lane);
         // ---- PASS 2: master EQ (usb_audio.c:721-728) ----
         if (!(flags & IF_BYPASS_MASTER_EQ)) {
-            if (!(img->ch_bypassed & 1u)) run_bands_f32<TAIL, kBands>(xl, n, img->eq[0], lds_state + (sm.eq + 0) * kLanes + lane);
-            if (!(img->ch_bypassed & 2u)) run_bands_f32<TAIL, kBands>(xr, n, img->eq[1], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
+            if (!(img->ch_bypassed & 1u)) run_bands<TAIL, kBands>(xl, n, img->eq[0], lds_state + (sm.eq + 0) * kLanes + lane);
+            if (!(img->ch_bypassed & 2u)) run_bands<TAIL, kBands>(xr, n, img->eq[1], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
         }
         if (lev_on) {
             // ---- leveller pass 1: RMS envelopes (leveller.c:155-172), samples parked in the ring ----
             const float ar = img->lv_alpha_rms, nar = 1.0f - ar;
-            const uint32_t base = m.rp1 + c1 * T;
+            const uint32_t base = (m.rp1 + c1 * T) & (kRingLen - 1);
+            const bool flat = __all(base + T <= (uint32_t)kRingLen);
+            uint32_t *wl = ring + (size_t)base * kLanes;
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
                 m.env_l = ar * m.env_l + nar * (xl[i] * xl[i]);
                 m.env_r = ar * m.env_r + nar * (xr[i] * xr[i]);
                 if (active) {
-                    uint32_t pos = (base + i) & (kRingLen - 1);
-                    ring[(size_t)pos * 2 * kLanes] = as_u(xl[i]);
-                    ring[(size_t)pos * 2 * kLanes + kLanes] = as_u(xr[i]);
+                    if (flat) { wl[i * kLanes] = as_u(xl[i]); wl[(kRingLen + i) * kLanes] = as_u(xr[i]); }
+                    else {
+                        uint32_t pos = (base + i) & (kRingLen - 1);
+                        ring[(size_t)pos * kLanes] = as_u(xl[i]);
+                        ring[(size_t)(kRingLen + pos) * kLanes] = as_u(xr[i]);
+                    }
                 }
             }
             if (c1 == g.cpb - 1) {   // end of packet: gain decision (leveller.c:168-206)
@@ -406,12 +483,15 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
         uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * kLanes + lane;
         const uint32_t w0 = s.widx + cq * T;
         float dl[T];
+        const uint32_t wb = w0 & dmask, rb = (w0 - (uint32_t)dly) & dmask;
+        const bool w_flat = __all(wb + T <= (uint32_t)sm.max_delay), r_flat = __all(rb + T <= (uint32_t)sm.max_delay);
         if (dl_early) {
+            const uint32_t *rl = line + (size_t)rb * kLanes;
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
                 uint32_t u = 0;
-                if (active) u = line[(size_t)((w0 + i - (uint32_t)dly) & dmask) * kLanes];
+                if (active) u = r_flat ? rl[i * kLanes] : line[(size_t)((rb + i) & dmask) * kLanes];
                 dl[i] = as_f(u);
             }
         }
@@ -435,7 +515,7 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
             if (enabled) {
                 const int ch = 2 + o;
                 if (!muted && !((img->ch_bypassed >> ch) & 1u))
-                    run_bands_f32<TAIL, kBands>(x, n, img->eq[ch], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
+                    run_bands<TAIL, kBands>(x, n, img->eq[ch], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
                 float gain = muted ? 0.0f : img->out_gain_lin[o] * s.vmm;
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
@@ -446,10 +526,11 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
             }
             // ---- PASS 6: delay line (usb_audio.c:898-912); [position][lane] rows in HBM ----
             if (dl_early || dl_alias) {
+                uint32_t *wl = line + (size_t)wb * kLanes;
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
                     if (TAIL && i >= n) break;
-                    if (active) line[(size_t)((w0 + i) & dmask) * kLanes] = as_u(x[i]);
+                    if (active) { if (w_flat) wl[i * kLanes] = as_u(x[i]); else line[(size_t)((wb + i) & dmask) * kLanes] = as_u(x[i]); }
                     if (dl_early) x[i] = dl[i];
                 }
             } else if (dl_on) {      // delay shorter than a chunk: the reference's per-sample order
@@ -551,7 +632,13 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t stream = wg * kLanes + lane;
-    const bool active = ((item.mask >> lane) & 1ull) && stream < a.n_streams;
+    // Lanes that are not part of this launch (streams of another parameter image, or padding past n_streams; the
+    // host never sets those mask bits) are switched off ONCE by narrowing EXEC for the whole kernel: every vector
+    // instruction below — loads, stores, LDS traffic — is then masked for free, instead of wrapping each memory
+    // access in its own saveexec/branch pair.  All four waves of a workgroup share the mask (never zero), so every
+    // wave still reaches every barrier.
+    asm volatile("s_mov_b64 exec, %0" ::"s"(item.mask) : "memory");
+    constexpr bool active = true;
     ImgPtr img = to_const(a.img);
 
     uint32_t *gs = a.state + (size_t)wg * sm.n_slots * kLanes + lane;
@@ -578,6 +665,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         for (int v = 0; v < T / 4; ++v) m.pre[v] = u32x4{0, 0, 0, 0};
         m.clip = gs[(sm.clip + 0) * kLanes];
         uint32_t k1 = 0, c1 = 0, kq = 0, cq = 0;
+        WT_DECL;
         for (uint32_t st = 0; st < g.steps; ++st) {
             const bool do_p1 = st < g.items;
             const bool do_item = st >= g.lag && st < g.items + g.lag;
@@ -587,8 +675,11 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             }
             if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
             if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
+            WT_BEFORE_BARRIER;
             lds_barrier();
+            WT_AFTER_BARRIER;
         }
+        WT_FINISH(0);
         if (active) {
             gs[(sm.xfeed + 0) * kLanes] = as_u(m.lpL); gs[(sm.xfeed + 1) * kLanes] = as_u(m.lpR);
             gs[(sm.xfeed + 2) * kLanes] = as_u(m.apL); gs[(sm.xfeed + 3) * kLanes] = as_u(m.apR);
@@ -610,14 +701,18 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         s.vmm = 0.0f;
         s.clip = gs[(sm.clip + wave) * kLanes];
         uint32_t kq = 0, cq = 0;
+        WT_DECL;
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
                 output_item_f32<TAIL>(a, img, sm, g, s, lds_state, lds_pk, xch, wg, lane, stream, active, o_first, o_count, kq, cq, q);
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
+            WT_BEFORE_BARRIER;
             lds_barrier();
+            WT_AFTER_BARRIER;
         }
+        WT_FINISH(wave);
         if (active) {
             if (wave == 1) {
                 gs[sm.widx * kLanes] = s.widx;
@@ -721,5 +816,16 @@ hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStre
     else hipLaunchKernelGGL(state_init_kernel<0>, dim3(n_wg), dim3(kLanes), 0, stream, state, n_wg);
     return hipGetLastError();
 }
+
+#ifdef DSPI_WAVE_TIMING
+extern "C" int dspi_debug_wave_timing(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wave_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_timing), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 }  // namespace dspi

@@ -10,7 +10,9 @@ from pathlib import Path
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libdspi_mi355x.so"
+import os
+
+LIB_PATH = Path(os.environ.get("DSPI_LIB") or (Path(__file__).resolve().parent / "csrc" / "libdspi_mi355x.so"))
 
 ALL = -1
 MEM_DEVICE = 0x1

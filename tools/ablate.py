@@ -25,7 +25,15 @@ def run(label, blob, outputs=True, steps=4):
         d.process_device(pcm.data_ptr(), NB, B, 16, *args)
     d.sync()
     dt = (time.perf_counter() - t0) / steps
-    print(f'{label:44s} {dt * 1e3:8.2f} ms/step  {S * NB * B / dt / 1e9:7.2f} Gframes/s', flush=True)
+    extra = ''
+    if os.environ.get('DSPI_LIB', '').endswith('timing.so'):
+        import ctypes
+        buf = (ctypes.c_ulonglong * 8)()
+        d.L.dspi_debug_wave_timing(buf, 1)
+        nwg = (S + 63) // 64
+        per = [buf[i] / nwg / (steps + 1) for i in range(8)]      # cycles per workgroup per launch
+        extra = '  busy/total Mcyc per WG: ' + ' '.join(f'w{w}:{per[2*w]/1e6:.2f}/{per[2*w+1]/1e6:.2f}' for w in range(4))
+    print(f'{label:44s} {dt * 1e3:8.2f} ms/step  {S * NB * B / dt / 1e9:7.2f} Gframes/s{extra}', flush=True)
     d.close()
 
 
