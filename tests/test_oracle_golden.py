@@ -1,0 +1,65 @@
+"""The standalone oracle restatement reproduces the golden vectors generated from oracle/_ref, i.e. from the
+reference's own leaf C sources compiled in place (tests/golden/make_golden.py).  CPU only, no reference needed.
+
+The _ref objects are x86-64 builds of the reference sources, whose out-of-range float->int casts yield INT_MIN
+(cvttss2si) where the MCUs saturate; the oracle reproduces that with x86_casts=True (oracle/orc_common.h), and the
+firmware (saturating) semantics — the ones the GPU is held to — are checked to coincide wherever no cast overflows."""
+import glob
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from orclib import Oracle
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def run(g, x86):
+    o = Oracle(int(g["flavor"]), ref=False, detmath=bool(g["detmath"]), x86_casts=x86)
+    assert o.set_rate(int(g["fs"])) == 0
+    o.set_volume(int(g["volume"]))
+    assert o.load_bulk(g["blob"].tobytes()) == 0
+    out = o.process(g["pcm"], int(g["blocks"]), int(g["block_len"]), int(g["bit_depth"]))
+    return out, o.status()
+
+
+def test_golden_present():
+    assert len(GOLDEN) >= 10
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_reference_golden(path):
+    g = np.load(path)
+    (pairs, sub, peaks, clip), status = run(g, x86=True)
+    assert crc(pairs) == int(g["pairs_crc"])
+    assert crc(sub) == int(g["sub_crc"])
+    assert crc(peaks) == int(g["peaks_crc"])
+    assert clip == int(g["clip"])
+    assert np.array_equal(pairs[:, :96], g["pairs_head"]) and np.array_equal(pairs[:, -96:], g["pairs_tail"])
+    assert np.array_equal(sub[:96], g["sub_head"]) and np.array_equal(sub[-96:], g["sub_tail"])
+    assert np.array_equal(peaks, g["peaks"])
+    assert np.frombuffer(status, dtype=np.uint8).tolist() == g["status"].tolist()
+
+
+@pytest.mark.parametrize("path", [p for p in GOLDEN if "q28_full_48k_detmath" not in p], ids=lambda p: os.path.basename(p)[:-4])
+def test_firmware_cast_semantics_agree_when_nothing_overflows(path):
+    g = np.load(path)
+    (p1, s1, k1, c1), _ = run(g, x86=True)
+    (p2, s2, k2, c2), _ = run(g, x86=False)
+    assert np.array_equal(p1, p2) and np.array_equal(s1, s2) and np.array_equal(k1, k2) and c1 == c2
+
+
+def test_q28_limiter_cast_is_the_documented_divergence():
+    """leveller.c:376: (int32_t)(ceil/peak * 2^28) overflows for peak < 0.0885 while boosting.  x86 -> INT_MIN -> gain
+    forced to unity; Cortex-M / RP2040 bootrom -> saturates -> gain kept.  The two must differ on this vector, and only
+    through that path (the float flavour has no such cast)."""
+    g = np.load([p for p in GOLDEN if "q28_full_48k_detmath" in p][0])
+    (p1, _, _, _), _ = run(g, x86=True)
+    (p2, _, _, _), _ = run(g, x86=False)
+    assert not np.array_equal(p1, p2)
