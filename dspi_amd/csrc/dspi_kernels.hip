@@ -43,6 +43,14 @@ typedef const __attribute__((address_space(4))) DevImage *ImgPtr;
 typedef const __attribute__((address_space(4))) DevBand *BandPtr;
 __device__ __forceinline__ ImgPtr to_const(const DevImage *p) { return (ImgPtr)(uintptr_t)p; }
 
+// (int32_t)float the way both MCUs do it (Cortex-M33 vcvt.s32.f32, RP2040 bootrom float2int_z): truncating, SATURATING,
+// NaN -> 0.  v_cvt_i32_f32 has exactly these semantics; going through asm keeps C's out-of-range UB out of the picture.
+__device__ __forceinline__ int32_t f2i_sat(float f) {
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+
 __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
@@ -571,12 +579,12 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
                     for (int v = 0; v < T / 4; ++v) {
                         u32x4 w;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) w[e] = live ? (uint32_t)(int32_t)(x[v * 4 + e] * 268435456.0f) : 0u;
+                        for (int e = 0; e < 4; ++e) w[e] = live ? (uint32_t)f2i_sat(x[v * 4 + e] * 268435456.0f) : 0u;
                         st4(dst + v * 4, w);
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < T; ++i) { if (i >= n) break; dst[i] = live ? (int32_t)(x[i] * 268435456.0f) : 0; }
+                    for (int i = 0; i < T; ++i) { if (i >= n) break; dst[i] = live ? f2i_sat(x[i] * 268435456.0f) : 0; }
                 }
             }
         } else {
@@ -602,6 +610,388 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
 #pragma unroll
                         for (int i = 0; i < T; ++i) { if (i >= n) break; dst[i * 2] = held[i]; dst[i * 2 + 1] = wv[i]; }
                     }
+                } else if (!(side == 0 && partner_here)) {
+#pragma unroll
+                    for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[i * 2 + side] = wv[i]; }
+                }
+            }
+            if (side == 0) {
+#pragma unroll
+                for (int i = 0; i < T; ++i) held[i] = wv[i];
+            }
+        }
+    }
+    if (cq == g.cpb - 1 && (flags & IF_ANY_DELAY)) s.widx = (s.widx + g.B) & ((uint32_t)sm.max_delay - 1u);
+}
+
+
+// ==========================================================================================
+// RP2040 Q28 flavour — integer arithmetic, every step wrapping mod 2^32 exactly as the Thumb code does
+// ==========================================================================================
+// fast_mul_q28 (dsp_pipeline.c:47-58, inlined 5x per sample in dsp_process_rp2040.S:63-77): NOT a 64-bit product.
+// The 16x16 partial products map onto v_mul_i32_i24 / v_mad_i32_i24 (full rate), no 64-bit multiplies.
+__device__ __forceinline__ int32_t qmul(int32_t a, int32_t b) {
+    int32_t ah = a >> 16, bh = b >> 16;
+    uint32_t al = (uint32_t)a & 0xFFFFu, bl = (uint32_t)b & 0xFFFFu;
+    uint32_t high = (uint32_t)(ah * bh);
+    int32_t mid = (int32_t)((uint32_t)ah * bl + al * (uint32_t)bh);
+    return (int32_t)((high << 4) + (uint32_t)(mid >> 12));
+}
+// fast_mul_q15 (config.h:556-567)
+__device__ __forceinline__ int32_t q15mul(int32_t sample, int32_t gain) {
+    int32_t sh = sample >> 16, gh = gain >> 16;
+    uint32_t sl = (uint32_t)sample & 0xFFFFu, gl = (uint32_t)gain & 0xFFFFu;
+    uint32_t hh = (uint32_t)(sh * gh);
+    uint32_t mid = (uint32_t)sh * gl + sl * (uint32_t)gh;
+    uint32_t ll = sl * gl;
+    return (int32_t)((hh << 17) + (mid << 1) + (ll >> 15));
+}
+__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int32_t wabs(int32_t a) { return a < 0 ? (int32_t)(0u - (uint32_t)a) : a; }
+// TDF2 cascade of dsp_process_rp2040.S:225-394 with the state pair in LDS; operands of band b+1 fetched during band b
+template <bool TAIL, int NB>
+__device__ __forceinline__ void run_bands_q28(int32_t (&x)[T], int n, BandPtr bands, int32_t *__restrict__ st) {
+    uint32_t kind = bands[0].kind;
+    int32_t b0 = bands[0].c[0].i, b1 = bands[0].c[1].i, b2 = bands[0].c[2].i, a1 = bands[0].c[3].i, a2 = bands[0].c[4].i;
+    int32_t s1 = st[0], s2 = st[kLanes];
+    asm volatile("" ::"s"(kind), "s"(b0), "s"(b1), "s"(b2), "s"(a1), "s"(a2), "v"(s1), "v"(s2));
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+        const int bn = (b + 1 < NB) ? b + 1 : b;
+        BandPtr nb = bands + bn;
+        const uint32_t nkind = nb->kind;
+        const int32_t n0 = nb->c[0].i, n1 = nb->c[1].i, n2 = nb->c[2].i, n3 = nb->c[3].i, n4 = nb->c[4].i;
+        const int32_t ns1 = st[bn * 2 * kLanes], ns2 = st[bn * 2 * kLanes + kLanes];
+        if (kind != K_BYPASS) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                const int32_t in = x[i];
+                const int32_t y = wadd(qmul(b0, in), s1);
+                const int32_t t1 = qmul(b1, in), t3 = qmul(b2, in);
+                const int32_t t2 = qmul(a1, y), t4 = qmul(a2, y);
+                s1 = wadd(wsub(t1, t2), s2);
+                s2 = wsub(t3, t4);
+                x[i] = y;
+            }
+            st[b * 2 * kLanes] = s1;
+            st[b * 2 * kLanes + kLanes] = s2;
+        }
+        kind = nkind; b0 = n0; b1 = n1; b2 = n2; a1 = n3; a2 = n4; s1 = ns1; s2 = ns2;
+    }
+}
+
+struct MasterQ28 {
+    int32_t lpL, lpR, apL, apR;
+    int32_t env_l, env_r;
+    float gsm_db;
+    int32_t g_cur, g_prev;
+    uint32_t rp1, rp2;
+    // pass-2 gain ramp: gain_i = g_prev + trunc((g_cur - g_prev) * i / (B-1)) (leveller.c:352) kept exact without 64-bit
+    // division: (g_cur-g_prev) = D*(B-1) + R  ->  gain_i = g_prev + D*i + trunc(R*i/(B-1)), the last term carried incrementally
+    int32_t p2_base, p2_D, p2_R, p2_acc, p2_carry;
+    int32_t pk_l, pk_r;
+    uint32_t clip;
+};
+
+template <bool TAIL>
+__device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g, MasterQ28 &m,
+                                                int32_t *__restrict__ lds_state, int32_t *__restrict__ xch_base, uint32_t wg, uint32_t lane, uint32_t stream,
+                                                bool do_p1, uint32_t k1, uint32_t c1, bool do_item, uint32_t kq, uint32_t cq, uint32_t q) {
+    const uint32_t flags = img->flags;
+    const bool lev_on = flags & IF_LEVELLER_ON;
+    int32_t xl[T], xr[T];
+    uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * kLanes + lane;
+    const int nq = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
+    const int32_t unity = 1 << 28;
+
+    int32_t ol[T], orr[T];
+    if (lev_on && do_item) {
+        if (cq == 0) {
+            const int32_t d = wsub(m.g_cur, m.g_prev);
+            if (g.B == 1) { m.p2_base = m.g_cur; m.p2_D = 0; m.p2_R = 0; }
+            else { const int32_t mm = (int32_t)g.B - 1; m.p2_base = m.g_prev; m.p2_D = d / mm; m.p2_R = d % mm; }
+            m.p2_acc = 0; m.p2_carry = 0;
+        }
+        const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
+        const uint32_t base = (m.rp2 + cq * T - back) & (kRingLen - 1);
+        const bool flat = __all(base + T <= (uint32_t)kRingLen);
+        const uint32_t *rl = ring + (size_t)base * kLanes;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (TAIL && i >= nq) break;
+            if (flat) { ol[i] = (int32_t)rl[i * kLanes]; orr[i] = (int32_t)rl[(kRingLen + i) * kLanes]; }
+            else { uint32_t pos = (base + i) & (kRingLen - 1); ol[i] = (int32_t)ring[(size_t)pos * kLanes]; orr[i] = (int32_t)ring[(size_t)(kRingLen + pos) * kLanes]; }
+        }
+    }
+
+    if (do_p1) {
+        const int n = TAIL ? (int)min((uint32_t)T, g.B - c1 * T) : T;
+        // ---- PASS 1: input conversion + preamp (usb_audio.c:997-1015) ----
+        const size_t frame0 = ((size_t)stream * g.n_blocks + k1) * g.B + (size_t)c1 * T;
+        const int32_t pl = img->preamp[0].i, pr = img->preamp[1].i;
+        if (a.bit_depth == 24) {
+            const uint16_t *p = reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(a.pcm) + frame0 * 6);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                uint32_t w0 = p[i * 3], w1 = p[i * 3 + 1], w2 = p[i * 3 + 2];
+                int32_t l = (int32_t)((w0 | (w1 << 16)) << 8) >> 2;          // 24-bit left-justified, then >>2: net <<6
+                int32_t r = (int32_t)(((w1 >> 8) | (w2 << 8)) << 8) >> 2;
+                xl[i] = qmul(l, pl);
+                xr[i] = qmul(r, pr);
+            }
+        } else {
+            const uint32_t *p = static_cast<const uint32_t *>(a.pcm) + frame0;
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                const uint32_t w = p[i];
+                xl[i] = qmul((int32_t)((uint32_t)(int32_t)(int16_t)(w & 0xffffu) << 14), pl);
+                xr[i] = qmul((int32_t)((uint32_t)((int32_t)w >> 16) << 14), pr);
+            }
+        }
+        // ---- loudness (usb_audio.c:1017-1047) and master EQ (:1049-1055) ----
+        run_bands_q28<TAIL, 2>(xl, n, img->loud, lds_state + (sm.loud + 0) * kLanes + lane);
+        run_bands_q28<TAIL, 2>(xr, n, img->loud, lds_state + (sm.loud + 4) * kLanes + lane);
+        if (!(flags & IF_BYPASS_MASTER_EQ)) {
+            if (!(img->ch_bypassed & 1u)) run_bands_q28<TAIL, kBands>(xl, n, img->eq[0], lds_state + (sm.eq + 0) * kLanes + lane);
+            if (!(img->ch_bypassed & 2u)) run_bands_q28<TAIL, kBands>(xr, n, img->eq[1], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
+        }
+        if (lev_on) {
+            // ---- leveller pass 1 (leveller.c:282-302) ----
+            const int32_t aq = img->lv_alpha_rms_q28, naq = unity - aq;
+            const uint32_t base = (m.rp1 + c1 * T) & (kRingLen - 1);
+            const bool flat = __all(base + T <= (uint32_t)kRingLen);
+            uint32_t *wl = ring + (size_t)base * kLanes;
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                const int32_t ql = qmul(xl[i], xl[i]), qr = qmul(xr[i], xr[i]);
+                m.env_l = wadd(qmul(aq, m.env_l), qmul(naq, ql));
+                m.env_r = wadd(qmul(aq, m.env_r), qmul(naq, qr));
+                if (flat) { wl[i * kLanes] = (uint32_t)xl[i]; wl[(kRingLen + i) * kLanes] = (uint32_t)xr[i]; }
+                else { uint32_t pos = (base + i) & (kRingLen - 1); ring[(size_t)pos * kLanes] = (uint32_t)xl[i]; ring[(size_t)(kRingLen + pos) * kLanes] = (uint32_t)xr[i]; }
+            }
+            if (c1 == g.cpb - 1) {   // leveller.c:304-334
+                const float inv = 1.0f / (float)(1 << 28);
+                const float el = (float)m.env_l * inv, er = (float)m.env_r * inv;
+                const float gl = leveller_block_gain(img, m.gsm_db, el > er ? el : er, g.B);
+                m.g_prev = m.g_cur;
+                m.g_cur = f2i_sat(gl * (float)(1 << 28));
+                m.rp1 = (m.rp1 + g.B) & (kRingLen - 1);
+            }
+        }
+    }
+
+    if (!do_item) return;
+    if (lev_on) {
+        // ---- leveller pass 2 (leveller.c:336-386) ----
+        const float inv = 1.0f / (float)(1 << 28);
+        const int32_t mm = (int32_t)g.B - 1;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (TAIL && i >= nq) break;
+            int32_t gain = wadd(m.p2_base, m.p2_carry);
+            if (gain > unity) {
+                float peak = fabsf((float)ol[i] * inv), prk = fabsf((float)orr[i] * inv);
+                if (prk > peak) peak = prk;
+                if (peak > 0.0f) {
+                    const float mgf = 0.70795f / peak;
+                    const int32_t mgq = f2i_sat(mgf * (float)unity);
+                    if (mgq < gain) gain = (mgq > unity) ? mgq : unity;
+                }
+            }
+            xl[i] = qmul(ol[i], gain);
+            xr[i] = qmul(orr[i], gain);
+            // advance the ramp to sample i+1
+            m.p2_base = wadd(m.p2_base, m.p2_D);
+            m.p2_acc += m.p2_R;
+            if (m.p2_acc >= mm && mm > 0) { m.p2_acc -= mm; m.p2_carry += 1; }
+            else if (m.p2_acc <= -mm && mm > 0) { m.p2_acc += mm; m.p2_carry -= 1; }
+        }
+        if (cq == g.cpb - 1) m.rp2 = (m.rp2 + g.B) & (kRingLen - 1);
+    }
+    // ---- PASS 3: master peaks + crossfeed (usb_audio.c:1065-1073, crossfeed.c:161-180) ----
+    if (cq == 0) { m.pk_l = 0; m.pk_r = 0; }
+    const bool xf = flags & IF_CROSSFEED_ON;
+    const int32_t a0 = img->xf_lp_a0.i, b1 = img->xf_lp_b1.i, apa = img->xf_ap_a.i;
+    int32_t *xch = xch_base + (size_t)(q & 1u) * (2 * T * kLanes) + lane;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        if (TAIL && i >= nq) break;
+        int32_t ml = xl[i], mr = xr[i];
+        if (wabs(ml) > m.pk_l) m.pk_l = wabs(ml);
+        if (wabs(mr) > m.pk_r) m.pk_r = wabs(mr);
+        if (xf) {
+            const int32_t lpl = wadd(qmul(a0, ml), qmul(b1, m.lpL));
+            const int32_t lpr = wadd(qmul(a0, mr), qmul(b1, m.lpR));
+            m.lpL = lpl; m.lpR = lpr;
+            const int32_t apl = wadd(qmul(apa, lpl), m.apL);
+            m.apL = wsub(lpl, qmul(apa, apl));
+            const int32_t apr = wadd(qmul(apa, lpr), m.apR);
+            m.apR = wsub(lpr, qmul(apa, apr));
+            const int32_t dl = wadd(wsub(ml, lpl), apr), dr = wadd(wsub(mr, lpr), apl);
+            ml = dl; mr = dr;
+        }
+        xch[i * kLanes] = ml;
+        xch[(T + i) * kLanes] = mr;
+    }
+    if (cq == g.cpb - 1) {   // usb_audio.c:1279-1282
+        const uint32_t p0 = (uint32_t)(uint16_t)(m.pk_l >> 13), p1 = (uint32_t)(uint16_t)(m.pk_r >> 13);
+        if (m.pk_l > (1 << 28) + 268) m.clip |= 1u;
+        if (m.pk_r > (1 << 28) + 268) m.clip |= 2u;
+        uint32_t *gs = a.state + (size_t)wg * sm.n_slots * kLanes + lane;
+        gs[(sm.peaks + 0) * kLanes] = p0;
+        gs[(sm.peaks + 1) * kLanes] = p1;
+        if (a.peaks) { uint16_t *pp = a.peaks + ((size_t)stream * g.n_blocks + kq) * sm.n_ch; pp[0] = (uint16_t)p0; pp[1] = (uint16_t)p1; }
+    }
+}
+
+struct OutQ28 {
+    uint32_t widx, loading, counter;
+    float smooth;
+    int32_t vmm;      // vol_mul_master, Q15
+    uint32_t clip;
+};
+
+template <bool TAIL>
+__device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g, OutQ28 &s,
+                                                int32_t *__restrict__ lds_state, int32_t *__restrict__ lds_pk, const int32_t *__restrict__ xch_base,
+                                                uint32_t wg, uint32_t lane, uint32_t stream, int o_first, int o_count, uint32_t kq, uint32_t cq, uint32_t q) {
+    const uint32_t flags = img->flags;
+    const int n = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
+    const int N = sm.n_out;
+    if (cq == 0) {
+        // preset-mute envelope (usb_audio.c:466-498) and Q15 volumes (:975-980)
+        bool act = s.loading != 0;
+        if (act) { if (s.counter > g.B) s.counter -= g.B; else { s.counter = 0; s.loading = 0; } }
+        float target = act ? 0.0f : 1.0f;
+        float step = (float)g.B / (float)img->mute_transition;
+        if (step > 1.0f) step = 1.0f;
+        float gg = s.smooth;
+        if (gg < target) { gg += step; if (gg > target) gg = target; }
+        else if (gg > target) { gg -= step; if (gg < target) gg = target; }
+        s.smooth = gg;
+        int32_t mq = f2i_sat(gg * 32768.0f + 0.5f);
+        if (mq < 0) mq = 0;
+        if (mq > 32768) mq = 32768;
+        const int32_t vol = q15mul(img->vol.i, mq);
+        s.vmm = q15mul(vol, img->master.i);
+    }
+    const int32_t *xch = xch_base + (size_t)(q & 1u) * (2 * T * kLanes) + lane;
+    const bool sub_active = flags & IF_SUB_ACTIVE;
+    const size_t F = (size_t)g.n_blocks * g.B;
+    const size_t frame0 = (size_t)kq * g.B + (size_t)cq * T;
+    int32_t held[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) held[i] = 0;
+
+#pragma unroll 1
+    for (int j = 0; j < o_count; ++j) {
+        const int o = o_first + j;
+        const bool is_sub = (o == N - 1);
+        const bool processed = !is_sub || sub_active;
+        const bool enabled = (img->out_enabled >> o) & 1u;
+        const bool muted = (img->out_mute >> o) & 1u;
+        int32_t x[T];
+        const int32_t dly = img->delay_samples[o];
+        const bool dl_on = processed && (flags & IF_ANY_DELAY) && dly > 0;
+        const bool dl_alias = dl_on && dly >= sm.max_delay;
+        const bool dl_early = dl_on && !dl_alias && dly >= T;
+        const uint32_t dmask = (uint32_t)sm.max_delay - 1u;
+        uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * kLanes + lane;
+        const uint32_t w0 = s.widx + cq * T;
+        const uint32_t wb = w0 & dmask, rb = (w0 - (uint32_t)dly) & dmask;
+        const bool w_flat = __all(wb + T <= (uint32_t)sm.max_delay), r_flat = __all(rb + T <= (uint32_t)sm.max_delay);
+        int32_t dl[T];
+        if (dl_early) {
+            const uint32_t *rl = line + (size_t)rb * kLanes;
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dl[i] = (int32_t)(r_flat ? rl[i * kLanes] : line[(size_t)((rb + i) & dmask) * kLanes]); }
+        }
+        // ---- PASS 4: matrix mix, Q15 crosspoints (usb_audio.c:1076-1100) ----
+        const int32_t gl = img->mix[0][o].i, gr = img->mix[1][o].i;
+        if (enabled && gl != 0 && gr != 0) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = wadd(q15mul(xch[i * kLanes], gl), q15mul(xch[(T + i) * kLanes], gr)); }
+        } else if (enabled && gl != 0) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = q15mul(xch[i * kLanes], gl); }
+        } else if (enabled && gr != 0) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = q15mul(xch[(T + i) * kLanes], gr); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T; ++i) x[i] = 0;
+        }
+        if (processed) {
+            // ---- PASS 5: per-output EQ (gated by the master bypass on this flavour, usb_audio.c:1200) + Q15 gain ----
+            if (enabled) {
+                const int ch = 2 + o;
+                if (!muted && !(flags & IF_BYPASS_MASTER_EQ) && !((img->ch_bypassed >> ch) & 1u))
+                    run_bands_q28<TAIL, kBands>(x, n, img->eq[ch], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
+                const int32_t gain = muted ? 0 : f2i_sat(img->out_gain_lin[o] * (float)s.vmm);
+#pragma unroll
+                for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; const int32_t y = q15mul(x[i], gain); x[i] = (gain == 0) ? 0 : y; }
+            }
+            // ---- PASS 6: delay line (usb_audio.c:1216-1230) ----
+            if (dl_early || dl_alias) {
+                uint32_t *wl = line + (size_t)wb * kLanes;
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (TAIL && i >= n) break;
+                    if (w_flat) wl[i * kLanes] = (uint32_t)x[i]; else line[(size_t)((wb + i) & dmask) * kLanes] = (uint32_t)x[i];
+                    if (dl_early) x[i] = dl[i];
+                }
+            } else if (dl_on) {
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (TAIL && i >= n) break;
+                    const uint32_t w = (wb + i) & dmask;
+                    line[(size_t)w * kLanes] = (uint32_t)x[i];
+                    x[i] = (int32_t)line[(size_t)((w - (uint32_t)dly) & dmask) * kLanes];
+                }
+            }
+        }
+        // ---- PASS 7: peaks + output words (usb_audio.c:1232-1275) ----
+        int32_t *pkp = lds_pk + (2 + o) * kLanes + lane;
+        int32_t pk = (cq == 0) ? 0 : *pkp;
+        const bool metered = !is_sub || (sub_active && enabled);
+        if (metered) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; const int32_t av = wabs(x[i]); if (av > pk) pk = av; }
+        }
+        *pkp = pk;
+        if (cq == g.cpb - 1) {
+            const uint32_t p16 = metered ? (uint32_t)(uint16_t)(pk >> 13) : 0u;
+            if (metered && pk > (1 << 28) + 268) s.clip |= 1u << (2 + o);
+            a.state[((size_t)wg * sm.n_slots + sm.peaks + 2 + o) * kLanes + lane] = p16;
+            if (a.peaks) a.peaks[((size_t)stream * g.n_blocks + kq) * sm.n_ch + 2 + o] = (uint16_t)p16;
+        }
+        if (is_sub) {
+            if (a.sub) {
+                int32_t *dst = a.sub + (size_t)stream * F + frame0;
+                const bool live = sub_active && enabled;
+#pragma unroll
+                for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[i] = live ? x[i] : 0; }
+            }
+        } else {
+            int32_t wv[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                if (TAIL && i >= n) break;
+                int32_t v = wadd(x[i], 1 << 5) >> 6;                                      // (x + 32) >> 6
+                wv[i] = v > 0x7FFFFF ? 0x7FFFFF : (v < -0x800000 ? -0x800000 : v);       // clip_s24
+            }
+            const int pair = o >> 1, side = o & 1;
+            const bool partner_here = side ? (j >= 1) : (j + 1 < o_count && o + 1 < N - 1);
+            if (a.pairs) {
+                int32_t *dst = a.pairs + (((size_t)stream * sm.n_pairs + pair) * F + frame0) * 2;
+                if (side == 1 && partner_here) {
+#pragma unroll
+                    for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[i * 2] = held[i]; dst[i * 2 + 1] = wv[i]; }
                 } else if (!(side == 0 && partner_here)) {
 #pragma unroll
                     for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[i * 2 + side] = wv[i]; }
@@ -652,7 +1042,60 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     g.lag = (img->flags & IF_LEVELLER_ON) ? g.cpb : 0u;
     g.steps = g.items + g.lag + 1;
 
-    if (wave == 0) {
+    if (wave == 0 && FLAVOR == 0) {
+        int32_t *qstate = reinterpret_cast<int32_t *>(lds);
+        int32_t *qxch = reinterpret_cast<int32_t *>(xch);
+        MasterQ28 m;
+        m.lpL = (int32_t)gs[(sm.xfeed + 0) * kLanes]; m.lpR = (int32_t)gs[(sm.xfeed + 1) * kLanes];
+        m.apL = (int32_t)gs[(sm.xfeed + 2) * kLanes]; m.apR = (int32_t)gs[(sm.xfeed + 3) * kLanes];
+        m.env_l = (int32_t)gs[(sm.lev + 0) * kLanes]; m.env_r = (int32_t)gs[(sm.lev + 1) * kLanes];
+        m.gsm_db = as_f(gs[(sm.lev + 2) * kLanes]); m.g_cur = (int32_t)gs[(sm.lev + 3) * kLanes]; m.g_prev = (int32_t)gs[(sm.lev + 4) * kLanes];
+        m.rp1 = m.rp2 = gs[sm.ring_pos * kLanes] & (kRingLen - 1);
+        m.p2_base = 1 << 28; m.p2_D = m.p2_R = m.p2_acc = m.p2_carry = 0; m.pk_l = m.pk_r = 0;
+        m.clip = gs[(sm.clip + 0) * kLanes];
+        uint32_t k1 = 0, c1 = 0, kq = 0, cq = 0;
+        for (uint32_t st = 0; st < g.steps; ++st) {
+            const bool do_p1 = st < g.items;
+            const bool do_item = st >= g.lag && st < g.items + g.lag;
+            const uint32_t q = st - g.lag;
+            if (do_p1 || do_item) master_step_q28<TAIL>(a, img, sm, g, m, qstate, qxch, wg, lane, stream, do_p1, k1, c1, do_item, kq, cq, q);
+            if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
+            if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
+            lds_barrier();
+        }
+        gs[(sm.xfeed + 0) * kLanes] = (uint32_t)m.lpL; gs[(sm.xfeed + 1) * kLanes] = (uint32_t)m.lpR;
+        gs[(sm.xfeed + 2) * kLanes] = (uint32_t)m.apL; gs[(sm.xfeed + 3) * kLanes] = (uint32_t)m.apR;
+        gs[(sm.lev + 0) * kLanes] = (uint32_t)m.env_l; gs[(sm.lev + 1) * kLanes] = (uint32_t)m.env_r;
+        gs[(sm.lev + 2) * kLanes] = as_u(m.gsm_db); gs[(sm.lev + 3) * kLanes] = (uint32_t)m.g_cur; gs[(sm.lev + 4) * kLanes] = (uint32_t)m.g_prev;
+        gs[sm.ring_pos * kLanes] = m.rp1;
+        gs[(sm.clip + 0) * kLanes] = m.clip;
+    } else if (FLAVOR == 0) {
+        int32_t *qstate = reinterpret_cast<int32_t *>(lds);
+        int32_t *qpk = reinterpret_cast<int32_t *>(lds_pk);
+        const int32_t *qxch = reinterpret_cast<const int32_t *>(xch);
+        // 5 outputs over waves 1..3: pair 0, pair 1, sub
+        const int o_first = (wave - 1) * 2;
+        const int o_count = (wave <= sm.n_pairs) ? 2 : 1;
+        OutQ28 s;
+        s.widx = gs[sm.widx * kLanes];
+        s.loading = gs[(sm.mute + 0) * kLanes]; s.counter = gs[(sm.mute + 1) * kLanes]; s.smooth = as_f(gs[(sm.mute + 2) * kLanes]);
+        s.vmm = 0;
+        s.clip = gs[(sm.clip + wave) * kLanes];
+        uint32_t kq = 0, cq = 0;
+        for (uint32_t st = 0; st < g.steps; ++st) {
+            if (st >= g.lag + 1) {
+                const uint32_t q = st - g.lag - 1;
+                output_item_q28<TAIL>(a, img, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
+                if (++cq == g.cpb) { cq = 0; ++kq; }
+            }
+            lds_barrier();
+        }
+        if (wave == 1) {
+            gs[sm.widx * kLanes] = s.widx;
+            gs[(sm.mute + 0) * kLanes] = s.loading; gs[(sm.mute + 1) * kLanes] = s.counter; gs[(sm.mute + 2) * kLanes] = as_u(s.smooth);
+        }
+        gs[(sm.clip + wave) * kLanes] = s.clip;
+    } else if (wave == 0) {
         MasterF32 m;
         m.lpL = as_f(gs[(sm.xfeed + 0) * kLanes]); m.lpR = as_f(gs[(sm.xfeed + 1) * kLanes]);
         m.apL = as_f(gs[(sm.xfeed + 2) * kLanes]); m.apR = as_f(gs[(sm.xfeed + 3) * kLanes]);
@@ -789,19 +1232,23 @@ size_t chain_lds_bytes(int flavor) {
     return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T) * kLanes * sizeof(uint32_t);
 }
 
-hipError_t launch_chain(int flavor, const KArgs &args, uint32_t n_items, hipStream_t stream) {
-    if (flavor != 1) return hipErrorNotSupported;   // Q28 kernel: see DESIGN.md (round plan)
-    const size_t lds = chain_lds_bytes(flavor);
+template <int FLAVOR>
+static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    const size_t lds = chain_lds_bytes(FLAVOR);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<1, true>), dim3(n_items), dim3(256), lds, stream, args);
-    else hipLaunchKernelGGL((chain_kernel<1, false>), dim3(n_items), dim3(256), lds, stream, args);
+    if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<FLAVOR, true>), dim3(n_items), dim3(256), lds, stream, args);
+    else hipLaunchKernelGGL((chain_kernel<FLAVOR, false>), dim3(n_items), dim3(256), lds, stream, args);
     return hipGetLastError();
+}
+
+hipError_t launch_chain(int flavor, const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    return flavor ? launch_chain_t<1>(args, n_items, stream) : launch_chain_t<0>(args, n_items, stream);
 }
 
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,

@@ -119,7 +119,7 @@ def test_per_stream_presets_and_clip_flags():
     blob = WL.full_chain_blob(1)
     for x in [d] + o:
         x.set_rate(fs); x.set_volume(-2 * 256); x.load_bulk(blob)
-    special = {3: -12.0, 64: 6.0, 69: 0.0}
+    special = {3: -12.0, 19: 20.0, 64: 6.0, 69: 0.0}       # +20 dB on the full-scale square stream: guaranteed clip flags
     for s, db in special.items():
         d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", db), stream=s)
         o[s].vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", db))

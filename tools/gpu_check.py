@@ -50,5 +50,9 @@ if __name__ == '__main__':
     ok &= parity(1, 96000, 96, 12, 70, WL.full_chain_blob(1), label='config3 full chain')
     ok &= parity(1, 44100, 45, 12, 5, WL.full_chain_blob(1), label='full chain 44.1k B=45 (tail path)')
     ok &= parity(1, 48000, 48, 12, 5, WL.full_chain_blob(1), bit_depth=24, label='full chain 24-bit')
-    ok &= parity(1, 96000, 96, 12, 3, WL.full_chain_blob(1), vol=0, label='full chain vol 0 dB (sign quirk)')
+    ok &= parity(1, 96000, 96, 12, 3, WL.full_chain_blob(1), vol=0, label="full chain vol 0 dB (sign quirk)")
+    ok &= parity(0, 48000, 48, 20, 8, WL.config1_blob(), vol=-10 * 256, label="Q28 config1")
+    ok &= parity(0, 48000, 48, 12, 70, WL.full_chain_blob(0), label="Q28 full chain (config 5)")
+    ok &= parity(0, 44100, 45, 12, 5, WL.full_chain_blob(0), bit_depth=24, label="Q28 full chain 44.1k 24-bit tail")
+    ok &= parity(0, 48000, 48, 12, 3, WL.full_chain_blob(0), vol=0, label="Q28 vol 0 dB")
     print('ALL OK' if ok else 'FAILURES')
