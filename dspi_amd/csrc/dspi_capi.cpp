@@ -31,8 +31,10 @@ struct dspi_ctx {
     std::vector<uint32_t> image_refs;
     std::vector<int32_t> stream_image;
     bool assignment_dirty = true;
-    std::vector<std::vector<WgItem>> image_items;   // per image: workgroups + lane masks
-    std::vector<uint32_t> image_item_offset;
+    // per image, four work lists (dspi_image.h:WgItem): 0 = all streams of the image (state ops; the Q28 chain launch),
+    // 1 = lanes whose two streams both belong (float: packed kernel), 2/3 = lanes where only stream 0 / 1 belongs
+    std::vector<std::vector<WgItem>> image_items[4];
+    std::vector<uint32_t> image_item_offset[4];
     // device
     hipStream_t hs = nullptr;
     uint32_t *d_state = nullptr, *d_dlines = nullptr, *d_ring = nullptr;
@@ -109,23 +111,39 @@ int ensure(dspi_ctx *c, P *&ptr, size_t &cap, size_t bytes) {
 
 int rebuild_assignment(dspi_ctx *c) {
     const size_t ni = c->images.size();
-    c->image_items.assign(ni, {});
-    std::vector<int32_t> last(ni, -1);
+    const uint32_t row = (uint32_t)c->sm.row;
+    const bool two = c->flavor != 0;                 // float flavour: two streams per lane
+    struct Acc { uint32_t wg; uint64_t m0, m1; };
+    std::vector<std::vector<Acc>> acc(ni);
     for (uint32_t s = 0; s < c->n_streams; s++) {
-        size_t im = (size_t)c->stream_image[s];
-        uint32_t wg = s / kLanes, lane = s % kLanes;
-        auto &v = c->image_items[im];
-        if (last[im] != (int32_t)wg) { v.push_back(WgItem{wg, 0u, 0ull}); last[im] = (int32_t)wg; }
-        v.back().mask |= 1ull << lane;
+        const size_t im = (size_t)c->stream_image[s];
+        const uint32_t wg = s / row, col = s % row;
+        auto &v = acc[im];
+        if (v.empty() || v.back().wg != wg) v.push_back(Acc{wg, 0ull, 0ull});
+        if (two) { if (col & 1u) v.back().m1 |= 1ull << (col >> 1); else v.back().m0 |= 1ull << (col >> 1); }
+        else v.back().m0 |= 1ull << col;
     }
     size_t total = 0;
-    c->image_item_offset.assign(ni, 0);
-    for (size_t i = 0; i < ni; i++) { c->image_item_offset[i] = (uint32_t)total; total += c->image_items[i].size(); }
+    for (int k = 0; k < 4; k++) { c->image_items[k].assign(ni, {}); c->image_item_offset[k].assign(ni, 0); }
+    for (size_t i = 0; i < ni; i++)
+        for (const Acc &x : acc[i]) {
+            c->image_items[0][i].push_back(WgItem{x.wg, 0u, x.m0, x.m1});
+            if (two) {
+                const uint64_t both = x.m0 & x.m1, only0 = x.m0 & ~x.m1, only1 = x.m1 & ~x.m0;
+                if (both) c->image_items[1][i].push_back(WgItem{x.wg, 0u, both, both});
+                if (only0) c->image_items[2][i].push_back(WgItem{x.wg, 0u, only0, 0ull});
+                if (only1) c->image_items[3][i].push_back(WgItem{x.wg, 0u, only1, 0ull});
+            }
+        }
+    for (int k = 0; k < 4; k++)
+        for (size_t i = 0; i < ni; i++) { c->image_item_offset[k][i] = (uint32_t)total; total += c->image_items[k][i].size(); }
     int rc = ensure(c, c->d_items, c->d_items_cap, total * sizeof(WgItem));
     if (rc) return rc;
-    for (size_t i = 0; i < ni; i++)
-        if (!c->image_items[i].empty())
-            HIPCK(c, hipMemcpyAsync(c->d_items + c->image_item_offset[i], c->image_items[i].data(), c->image_items[i].size() * sizeof(WgItem), hipMemcpyHostToDevice, c->hs));
+    for (int k = 0; k < 4; k++)
+        for (size_t i = 0; i < ni; i++)
+            if (!c->image_items[k][i].empty())
+                HIPCK(c, hipMemcpyAsync(c->d_items + c->image_item_offset[k][i], c->image_items[k][i].data(), c->image_items[k][i].size() * sizeof(WgItem),
+                                        hipMemcpyHostToDevice, c->hs));
     HIPCK(c, hipStreamSynchronize(c->hs));
     c->assignment_dirty = false;
     return 0;
@@ -162,9 +180,9 @@ int commit_params(dspi_ctx *c) {
             p.dirty = false;
         }
         if (ops_pending(p.ops)) {
-            const auto &items = c->image_items[i];
+            const auto &items = c->image_items[0][i];
             if (!items.empty())
-                HIPCK(c, launch_state_ops(c->flavor, c->d_items + c->image_item_offset[i], (uint32_t)items.size(), p.ops, c->d_state, c->d_dlines,
+                HIPCK(c, launch_state_ops(c->flavor, c->d_items + c->image_item_offset[0][i], (uint32_t)items.size(), p.ops, c->d_state, c->d_dlines,
                                           c->d_ring, c->n_streams, c->hs));
             p.ops = StateOps{};
         }
@@ -173,10 +191,10 @@ int commit_params(dspi_ctx *c) {
 }
 
 int read_stream_words(dspi_ctx *c, uint32_t stream, int slot0, int count, uint32_t *out) {
-    const uint32_t wg = stream / kLanes, lane = stream % kLanes;
-    const uint32_t *src = c->d_state + ((size_t)wg * c->sm.n_slots + slot0) * kLanes + lane;
+    const uint32_t row = (uint32_t)c->sm.row, wg = stream / row, col = stream % row;
+    const uint32_t *src = c->d_state + ((size_t)wg * c->sm.n_slots + slot0) * row + col;
     HIPCK(c, hipStreamSynchronize(c->hs));
-    HIPCK(c, hipMemcpy2D(out, 4, src, kLanes * 4, 4, (size_t)count, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy2D(out, 4, src, (size_t)row * 4, 4, (size_t)count, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -196,13 +214,13 @@ int fetch_status(dspi_ctx *c, int32_t stream, uint16_t *peaks, uint16_t *clip) {
 int zero_clips(dspi_ctx *c, int32_t stream) {
     if (c->device == DSPI_DEVICE_NONE) return 0;
     HIPCK(c, hipStreamSynchronize(c->hs));
-    const size_t pitch = (size_t)c->sm.n_slots * kLanes * 4;
+    const size_t row = (size_t)c->sm.row, pitch = (size_t)c->sm.n_slots * row * 4;
     if (stream == DSPI_ALL_STREAMS) {
-        HIPCK(c, hipMemset2D(c->d_state + (size_t)c->sm.clip * kLanes, pitch, 0, 4 * kLanes * 4, c->n_wg));
+        HIPCK(c, hipMemset2D(c->d_state + (size_t)c->sm.clip * row, pitch, 0, 4 * row * 4, c->n_wg));
     } else {
-        const uint32_t wg = (uint32_t)stream / kLanes, lane = (uint32_t)stream % kLanes;
+        const uint32_t wg = (uint32_t)stream / (uint32_t)row, col = (uint32_t)stream % (uint32_t)row;
         uint32_t z[4] = {0, 0, 0, 0};
-        HIPCK(c, hipMemcpy2D(c->d_state + ((size_t)wg * c->sm.n_slots + c->sm.clip) * kLanes + lane, kLanes * 4, z, 4, 4, 4, hipMemcpyHostToDevice));
+        HIPCK(c, hipMemcpy2D(c->d_state + ((size_t)wg * c->sm.n_slots + c->sm.clip) * row + col, row * 4, z, 4, 4, 4, hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -219,9 +237,9 @@ int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) 
     if (!c) return DSPI_E_NOMEM;
     c->flavor = flavor;
     c->n_streams = n_streams;
-    c->n_wg = (n_streams + kLanes - 1) / kLanes;
     c->device = hip_device;
     c->sm = make_state_map(flavor);
+    c->n_wg = (n_streams + (uint32_t)c->sm.row - 1) / (uint32_t)c->sm.row;
     c->images.push_back(std::make_unique<Params>(flavor));
     c->image_refs.push_back(n_streams);
     c->stream_image.assign(n_streams, 0);
@@ -233,9 +251,10 @@ int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) 
     auto bail = [&](int code) { dspi_destroy(c); *out = nullptr; return code; };
     if (hipSetDevice(hip_device) != hipSuccess) return bail(DSPI_E_NODEVICE);
     if (hipStreamCreateWithFlags(&c->hs, hipStreamNonBlocking) != hipSuccess) return bail(DSPI_E_HIP);
-    const size_t state_b = (size_t)c->n_wg * c->sm.n_slots * kLanes * 4;
-    const size_t dl_b = (size_t)c->n_wg * c->sm.n_out * (size_t)c->sm.max_delay * kLanes * 4;
-    const size_t ring_b = (size_t)c->n_wg * kRingLen * 2 * kLanes * 4;
+    const size_t row = (size_t)c->sm.row;
+    const size_t state_b = (size_t)c->n_wg * c->sm.n_slots * row * 4;
+    const size_t dl_b = (size_t)c->n_wg * c->sm.n_out * (size_t)c->sm.max_delay * row * 4;
+    const size_t ring_b = (size_t)c->n_wg * kRingLen * 2 * row * 4;
     if (hipMalloc((void **)&c->d_state, state_b) != hipSuccess || hipMalloc((void **)&c->d_dlines, dl_b) != hipSuccess ||
         hipMalloc((void **)&c->d_ring, ring_b) != hipSuccess)
         return bail(DSPI_E_NOMEM);
@@ -381,12 +400,24 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         if (out->peaks) { if ((rc = ensure(c, c->d_peaks, c->d_peaks_cap, peaks_b))) return rc; a.peaks = c->d_peaks; }
     }
     for (size_t i = 0; i < c->images.size(); i++) {
-        if (c->image_refs[i] == 0 || c->image_items[i].empty()) continue;
+        if (c->image_refs[i] == 0) continue;
         a.img = c->d_images + i;
-        a.items = c->d_items + c->image_item_offset[i];
-        hipError_t e = launch_chain(c->flavor, a, (uint32_t)c->image_items[i].size(), c->hs);
-        if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
-        if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));
+        // float flavour: lanes with both streams in this image go to the packed kernel (list 1), lanes with one stream
+        // to the scalar kernel per component (lists 2, 3).  Q28: one scalar launch over list 0.
+        struct Launch { int list; int packed; uint32_t comp; };
+        static const Launch kF32[] = {{1, 1, 0}, {2, 0, 0}, {3, 0, 1}};
+        static const Launch kQ28[] = {{0, 0, 0}};
+        const Launch *ls = c->flavor ? kF32 : kQ28;
+        const int nl = c->flavor ? 3 : 1;
+        for (int l = 0; l < nl; l++) {
+            const auto &items = c->image_items[ls[l].list][i];
+            if (items.empty()) continue;
+            a.items = c->d_items + c->image_item_offset[ls[l].list][i];
+            a.comp = ls[l].comp;
+            hipError_t e = launch_chain(c->flavor, ls[l].packed, a, (uint32_t)items.size(), c->hs);
+            if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
+            if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));
+        }
     }
     if (!dev) {
         if (out->pairs) HIPCK(c, hipMemcpyAsync(out->pairs, c->d_pairs, pairs_b, hipMemcpyDeviceToHost, c->hs));

@@ -76,6 +76,7 @@ struct DevImage {
 // ------------------------------------------------------------------------------------------
 struct StateMap {
     int n_ch, n_out, n_pairs, max_delay;
+    int row;       // streams per workgroup = width of every [..][row] device array: 128 (float: 2 per lane) / 64 (Q28)
     int eq;        // (ch*kBands + band)*2 + {0,1}           : s1,s2  or ic1eq,ic2eq
     int loud;      // ((ch*2 + stage)*2 + {0,1}
     int lds_slots; // = loud + 8
@@ -95,6 +96,7 @@ constexpr StateMap make_state_map(int flavor) {
     m.n_out = flavor ? 9 : 5;
     m.n_pairs = flavor ? 4 : 2;
     m.max_delay = flavor ? 4096 : 2048;
+    m.row = flavor ? 128 : 64;
     m.eq = 0;
     m.loud = m.n_ch * kBands * 2;
     m.lds_slots = m.loud + 8;
@@ -125,7 +127,8 @@ struct StateOps {
 struct WgItem {
     uint32_t wg;
     uint32_t pad;
-    uint64_t mask;   // lanes of this workgroup that belong to the image being launched
+    uint64_t mask;   // lanes of this workgroup that take part in the launch
+    uint64_t mask1;  // state_ops only (float flavour): second stream of each lane; chain launches ignore it
 };
 
 }  // namespace dspi

@@ -20,10 +20,13 @@ struct KArgs {
     int32_t *sub;            // [stream][frames] or null
     uint16_t *peaks;         // [stream][block][C] or null
     uint32_t n_streams, n_blocks, block_len, bit_depth;
+    uint32_t comp;           // float flavour, scalar kernel: which of a lane's two streams (column = lane*2 + comp)
 };
 
 size_t chain_lds_bytes(int flavor);
-hipError_t launch_chain(int flavor, const KArgs &args, uint32_t n_items, hipStream_t stream);
+// packed != 0 (float flavour only): items list lanes whose two streams are both processed (v_pk kernel);
+// packed == 0: scalar kernel, one stream per lane (float: the stream args.comp of each listed lane)
+hipError_t launch_chain(int flavor, int packed, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
                             uint32_t *ring, uint32_t n_streams, hipStream_t stream);
 hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream);

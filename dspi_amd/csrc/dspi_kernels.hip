@@ -223,12 +223,13 @@ struct MasterF32 {
 template <bool TAIL>
 __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g,
                                                 MasterF32 &m, float *__restrict__ lds_state, float *__restrict__ xch_base,
-                                                uint32_t wg, uint32_t lane, uint32_t stream, bool active,
+                                                uint32_t wg, uint32_t lane, uint32_t col, uint32_t stream, bool active,
                                                 bool do_p1, uint32_t k1, uint32_t c1, bool do_item, uint32_t kq, uint32_t cq, uint32_t q) {
+    constexpr uint32_t ROW = make_state_map(1).row;   // global arrays are [..][row] with this stream in column `col`
     const uint32_t flags = img->flags;
     const bool lev_on = flags & IF_LEVELLER_ON;
     float xl[T], xr[T];
-    uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * kLanes + lane;
+    uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * ROW + col;
     const int nq = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
 
     // Pass-2 operands come out of the ring (written >= one packet ago): issue those loads first so
@@ -242,12 +243,12 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
         const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
         const uint32_t base = (m.rp2 + cq * T - back) & (kRingLen - 1);
         if (__all(base + T <= (uint32_t)kRingLen)) {          // no wrap inside the chunk: one base + immediate offsets
-            const uint32_t *rl = ring + (size_t)base * kLanes;
+            const uint32_t *rl = ring + (size_t)base * ROW;
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= nq) break;
                 uint32_t ul = 0, ur = 0;
-                if (active) { ul = rl[i * kLanes]; ur = rl[(kRingLen + i) * kLanes]; }
+                if (active) { ul = rl[i * ROW]; ur = rl[(kRingLen + i) * ROW]; }
                 ol[i] = as_f(ul);
                 orr[i] = as_f(ur);
             }
@@ -257,7 +258,7 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
                 if (TAIL && i >= nq) break;
                 uint32_t pos = (base + i) & (kRingLen - 1);
                 uint32_t ul = 0, ur = 0;
-                if (active) { ul = ring[(size_t)pos * kLanes]; ur = ring[(size_t)(kRingLen + pos) * kLanes]; }
+                if (active) { ul = ring[(size_t)pos * ROW]; ur = ring[(size_t)(kRingLen + pos) * ROW]; }
                 ol[i] = as_f(ul);
                 orr[i] = as_f(ur);
             }
@@ -328,18 +329,18 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
             const float ar = img->lv_alpha_rms, nar = 1.0f - ar;
             const uint32_t base = (m.rp1 + c1 * T) & (kRingLen - 1);
             const bool flat = __all(base + T <= (uint32_t)kRingLen);
-            uint32_t *wl = ring + (size_t)base * kLanes;
+            uint32_t *wl = ring + (size_t)base * ROW;
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
                 m.env_l = ar * m.env_l + nar * (xl[i] * xl[i]);
                 m.env_r = ar * m.env_r + nar * (xr[i] * xr[i]);
                 if (active) {
-                    if (flat) { wl[i * kLanes] = as_u(xl[i]); wl[(kRingLen + i) * kLanes] = as_u(xr[i]); }
+                    if (flat) { wl[i * ROW] = as_u(xl[i]); wl[(kRingLen + i) * ROW] = as_u(xr[i]); }
                     else {
                         uint32_t pos = (base + i) & (kRingLen - 1);
-                        ring[(size_t)pos * kLanes] = as_u(xl[i]);
-                        ring[(size_t)(kRingLen + pos) * kLanes] = as_u(xr[i]);
+                        ring[(size_t)pos * ROW] = as_u(xl[i]);
+                        ring[(size_t)(kRingLen + pos) * ROW] = as_u(xr[i]);
                     }
                 }
             }
@@ -408,9 +409,9 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
         if (m.pk_l > 1.001f) m.clip |= 1u;
         if (m.pk_r > 1.001f) m.clip |= 2u;
         if (active) {
-            uint32_t *gs = a.state + (size_t)wg * sm.n_slots * kLanes + lane;
-            gs[(sm.peaks + 0) * kLanes] = p0;
-            gs[(sm.peaks + 1) * kLanes] = p1;
+            uint32_t *gs = a.state + (size_t)wg * sm.n_slots * ROW + col;
+            gs[(sm.peaks + 0) * ROW] = p0;
+            gs[(sm.peaks + 1) * ROW] = p1;
             if (a.peaks) {
                 uint16_t *pp = a.peaks + ((size_t)stream * g.n_blocks + kq) * sm.n_ch;
                 pp[0] = (uint16_t)p0; pp[1] = (uint16_t)p1;
@@ -433,8 +434,9 @@ struct OutF32 {
 template <bool TAIL>
 __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g,
                                                 OutF32 &s, float *__restrict__ lds_state, float *__restrict__ lds_pk, const float *__restrict__ xch_base,
-                                                uint32_t wg, uint32_t lane, uint32_t stream, bool active,
+                                                uint32_t wg, uint32_t lane, uint32_t col, uint32_t stream, bool active,
                                                 int o_first, int o_count, uint32_t kq, uint32_t cq, uint32_t q) {
+    constexpr uint32_t ROW = make_state_map(1).row;
     const uint32_t flags = img->flags;
     const int n = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
     const int N = sm.n_out;
@@ -488,18 +490,18 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
         const bool dl_alias = dl_on && dly >= sm.max_delay;          // reads back what it just wrote
         const bool dl_early = dl_on && !dl_alias && dly >= T;
         const uint32_t dmask = (uint32_t)sm.max_delay - 1u;
-        uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * kLanes + lane;
+        uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * ROW + col;
         const uint32_t w0 = s.widx + cq * T;
         float dl[T];
         const uint32_t wb = w0 & dmask, rb = (w0 - (uint32_t)dly) & dmask;
         const bool w_flat = __all(wb + T <= (uint32_t)sm.max_delay), r_flat = __all(rb + T <= (uint32_t)sm.max_delay);
         if (dl_early) {
-            const uint32_t *rl = line + (size_t)rb * kLanes;
+            const uint32_t *rl = line + (size_t)rb * ROW;
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
                 uint32_t u = 0;
-                if (active) u = r_flat ? rl[i * kLanes] : line[(size_t)((rb + i) & dmask) * kLanes];
+                if (active) u = r_flat ? rl[i * ROW] : line[(size_t)((rb + i) & dmask) * ROW];
                 dl[i] = as_f(u);
             }
         }
@@ -534,11 +536,11 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
             }
             // ---- PASS 6: delay line (usb_audio.c:898-912); [position][lane] rows in HBM ----
             if (dl_early || dl_alias) {
-                uint32_t *wl = line + (size_t)wb * kLanes;
+                uint32_t *wl = line + (size_t)wb * ROW;
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
                     if (TAIL && i >= n) break;
-                    if (active) { if (w_flat) wl[i * kLanes] = as_u(x[i]); else line[(size_t)((wb + i) & dmask) * kLanes] = as_u(x[i]); }
+                    if (active) { if (w_flat) wl[i * ROW] = as_u(x[i]); else line[(size_t)((wb + i) & dmask) * ROW] = as_u(x[i]); }
                     if (dl_early) x[i] = dl[i];
                 }
             } else if (dl_on) {      // delay shorter than a chunk: the reference's per-sample order
@@ -547,8 +549,8 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
                     if (TAIL && i >= n) break;
                     uint32_t w = (w0 + i) & dmask;
                     if (active) {
-                        line[(size_t)w * kLanes] = as_u(x[i]);
-                        x[i] = as_f(line[(size_t)((w - (uint32_t)dly) & dmask) * kLanes]);
+                        line[(size_t)w * ROW] = as_u(x[i]);
+                        x[i] = as_f(line[(size_t)((w - (uint32_t)dly) & dmask) * ROW]);
                     }
                 }
             }
@@ -566,7 +568,7 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
             uint32_t p16 = metered ? (uint32_t)(fminf(1.0f, pk) * 32767.0f) : 0u;
             if (metered && pk > 1.001f) s.clip |= 1u << (2 + o);
             if (active) {
-                a.state[((size_t)wg * sm.n_slots + sm.peaks + 2 + o) * kLanes + lane] = p16;
+                a.state[((size_t)wg * sm.n_slots + sm.peaks + 2 + o) * ROW + col] = p16;
                 if (a.peaks) a.peaks[((size_t)stream * g.n_blocks + kq) * sm.n_ch + 2 + o] = (uint16_t)p16;
             }
         }
@@ -699,10 +701,12 @@ template <bool TAIL>
 __device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g, MasterQ28 &m,
                                                 int32_t *__restrict__ lds_state, int32_t *__restrict__ xch_base, uint32_t wg, uint32_t lane, uint32_t stream,
                                                 bool do_p1, uint32_t k1, uint32_t c1, bool do_item, uint32_t kq, uint32_t cq, uint32_t q) {
+    constexpr uint32_t ROW = make_state_map(0).row;
+    const uint32_t col = lane;
     const uint32_t flags = img->flags;
     const bool lev_on = flags & IF_LEVELLER_ON;
     int32_t xl[T], xr[T];
-    uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * kLanes + lane;
+    uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * ROW + col;
     const int nq = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
     const int32_t unity = 1 << 28;
 
@@ -717,12 +721,12 @@ __device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, cons
         const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
         const uint32_t base = (m.rp2 + cq * T - back) & (kRingLen - 1);
         const bool flat = __all(base + T <= (uint32_t)kRingLen);
-        const uint32_t *rl = ring + (size_t)base * kLanes;
+        const uint32_t *rl = ring + (size_t)base * ROW;
 #pragma unroll
         for (int i = 0; i < T; ++i) {
             if (TAIL && i >= nq) break;
-            if (flat) { ol[i] = (int32_t)rl[i * kLanes]; orr[i] = (int32_t)rl[(kRingLen + i) * kLanes]; }
-            else { uint32_t pos = (base + i) & (kRingLen - 1); ol[i] = (int32_t)ring[(size_t)pos * kLanes]; orr[i] = (int32_t)ring[(size_t)(kRingLen + pos) * kLanes]; }
+            if (flat) { ol[i] = (int32_t)rl[i * ROW]; orr[i] = (int32_t)rl[(kRingLen + i) * ROW]; }
+            else { uint32_t pos = (base + i) & (kRingLen - 1); ol[i] = (int32_t)ring[(size_t)pos * ROW]; orr[i] = (int32_t)ring[(size_t)(kRingLen + pos) * ROW]; }
         }
     }
 
@@ -764,15 +768,15 @@ __device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, cons
             const int32_t aq = img->lv_alpha_rms_q28, naq = unity - aq;
             const uint32_t base = (m.rp1 + c1 * T) & (kRingLen - 1);
             const bool flat = __all(base + T <= (uint32_t)kRingLen);
-            uint32_t *wl = ring + (size_t)base * kLanes;
+            uint32_t *wl = ring + (size_t)base * ROW;
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
                 const int32_t ql = qmul(xl[i], xl[i]), qr = qmul(xr[i], xr[i]);
                 m.env_l = wadd(qmul(aq, m.env_l), qmul(naq, ql));
                 m.env_r = wadd(qmul(aq, m.env_r), qmul(naq, qr));
-                if (flat) { wl[i * kLanes] = (uint32_t)xl[i]; wl[(kRingLen + i) * kLanes] = (uint32_t)xr[i]; }
-                else { uint32_t pos = (base + i) & (kRingLen - 1); ring[(size_t)pos * kLanes] = (uint32_t)xl[i]; ring[(size_t)(kRingLen + pos) * kLanes] = (uint32_t)xr[i]; }
+                if (flat) { wl[i * ROW] = (uint32_t)xl[i]; wl[(kRingLen + i) * ROW] = (uint32_t)xr[i]; }
+                else { uint32_t pos = (base + i) & (kRingLen - 1); ring[(size_t)pos * ROW] = (uint32_t)xl[i]; ring[(size_t)(kRingLen + pos) * ROW] = (uint32_t)xr[i]; }
             }
             if (c1 == g.cpb - 1) {   // leveller.c:304-334
                 const float inv = 1.0f / (float)(1 << 28);
@@ -842,9 +846,9 @@ __device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, cons
         const uint32_t p0 = (uint32_t)(uint16_t)(m.pk_l >> 13), p1 = (uint32_t)(uint16_t)(m.pk_r >> 13);
         if (m.pk_l > (1 << 28) + 268) m.clip |= 1u;
         if (m.pk_r > (1 << 28) + 268) m.clip |= 2u;
-        uint32_t *gs = a.state + (size_t)wg * sm.n_slots * kLanes + lane;
-        gs[(sm.peaks + 0) * kLanes] = p0;
-        gs[(sm.peaks + 1) * kLanes] = p1;
+        uint32_t *gs = a.state + (size_t)wg * sm.n_slots * ROW + col;
+        gs[(sm.peaks + 0) * ROW] = p0;
+        gs[(sm.peaks + 1) * ROW] = p1;
         if (a.peaks) { uint16_t *pp = a.peaks + ((size_t)stream * g.n_blocks + kq) * sm.n_ch; pp[0] = (uint16_t)p0; pp[1] = (uint16_t)p1; }
     }
 }
@@ -860,6 +864,8 @@ template <bool TAIL>
 __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g, OutQ28 &s,
                                                 int32_t *__restrict__ lds_state, int32_t *__restrict__ lds_pk, const int32_t *__restrict__ xch_base,
                                                 uint32_t wg, uint32_t lane, uint32_t stream, int o_first, int o_count, uint32_t kq, uint32_t cq, uint32_t q) {
+    constexpr uint32_t ROW = make_state_map(0).row;
+    const uint32_t col = lane;
     const uint32_t flags = img->flags;
     const int n = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
     const int N = sm.n_out;
@@ -901,15 +907,15 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
         const bool dl_alias = dl_on && dly >= sm.max_delay;
         const bool dl_early = dl_on && !dl_alias && dly >= T;
         const uint32_t dmask = (uint32_t)sm.max_delay - 1u;
-        uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * kLanes + lane;
+        uint32_t *line = a.dlines + ((size_t)wg * N + o) * (size_t)sm.max_delay * ROW + col;
         const uint32_t w0 = s.widx + cq * T;
         const uint32_t wb = w0 & dmask, rb = (w0 - (uint32_t)dly) & dmask;
         const bool w_flat = __all(wb + T <= (uint32_t)sm.max_delay), r_flat = __all(rb + T <= (uint32_t)sm.max_delay);
         int32_t dl[T];
         if (dl_early) {
-            const uint32_t *rl = line + (size_t)rb * kLanes;
+            const uint32_t *rl = line + (size_t)rb * ROW;
 #pragma unroll
-            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dl[i] = (int32_t)(r_flat ? rl[i * kLanes] : line[(size_t)((rb + i) & dmask) * kLanes]); }
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dl[i] = (int32_t)(r_flat ? rl[i * ROW] : line[(size_t)((rb + i) & dmask) * ROW]); }
         }
         // ---- PASS 4: matrix mix, Q15 crosspoints (usb_audio.c:1076-1100) ----
         const int32_t gl = img->mix[0][o].i, gr = img->mix[1][o].i;
@@ -938,11 +944,11 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
             }
             // ---- PASS 6: delay line (usb_audio.c:1216-1230) ----
             if (dl_early || dl_alias) {
-                uint32_t *wl = line + (size_t)wb * kLanes;
+                uint32_t *wl = line + (size_t)wb * ROW;
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
                     if (TAIL && i >= n) break;
-                    if (w_flat) wl[i * kLanes] = (uint32_t)x[i]; else line[(size_t)((wb + i) & dmask) * kLanes] = (uint32_t)x[i];
+                    if (w_flat) wl[i * ROW] = (uint32_t)x[i]; else line[(size_t)((wb + i) & dmask) * ROW] = (uint32_t)x[i];
                     if (dl_early) x[i] = dl[i];
                 }
             } else if (dl_on) {
@@ -950,8 +956,8 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
                 for (int i = 0; i < T; ++i) {
                     if (TAIL && i >= n) break;
                     const uint32_t w = (wb + i) & dmask;
-                    line[(size_t)w * kLanes] = (uint32_t)x[i];
-                    x[i] = (int32_t)line[(size_t)((w - (uint32_t)dly) & dmask) * kLanes];
+                    line[(size_t)w * ROW] = (uint32_t)x[i];
+                    x[i] = (int32_t)line[(size_t)((w - (uint32_t)dly) & dmask) * ROW];
                 }
             }
         }
@@ -967,7 +973,7 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
         if (cq == g.cpb - 1) {
             const uint32_t p16 = metered ? (uint32_t)(uint16_t)(pk >> 13) : 0u;
             if (metered && pk > (1 << 28) + 268) s.clip |= 1u << (2 + o);
-            a.state[((size_t)wg * sm.n_slots + sm.peaks + 2 + o) * kLanes + lane] = p16;
+            a.state[((size_t)wg * sm.n_slots + sm.peaks + 2 + o) * ROW + col] = p16;
             if (a.peaks) a.peaks[((size_t)stream * g.n_blocks + kq) * sm.n_ch + 2 + o] = (uint16_t)p16;
         }
         if (is_sub) {
@@ -1021,7 +1027,11 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     const uint32_t wg = item.wg;
     const uint32_t lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t stream = wg * kLanes + lane;
+    // the float flavour keeps two streams per lane column pair (packed kernel); this scalar kernel then serves one
+    // component (a.comp) of the lanes whose two streams carry different parameter images
+    constexpr uint32_t ROW = sm.row;
+    const uint32_t col = FLAVOR ? lane * 2 + a.comp : lane;
+    const uint32_t stream = wg * ROW + col;
     // Lanes that are not part of this launch (streams of another parameter image, or padding past n_streams; the
     // host never sets those mask bits) are switched off ONCE by narrowing EXEC for the whole kernel: every vector
     // instruction below — loads, stores, LDS traffic — is then masked for free, instead of wrapping each memory
@@ -1031,8 +1041,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     constexpr bool active = true;
     ImgPtr img = to_const(a.img);
 
-    uint32_t *gs = a.state + (size_t)wg * sm.n_slots * kLanes + lane;
-    for (int s = wave; s < sm.lds_slots; s += 4) lds[s * kLanes + lane] = gs[(size_t)s * kLanes];
+    uint32_t *gs = a.state + (size_t)wg * sm.n_slots * ROW + col;
+    for (int s = wave; s < sm.lds_slots; s += 4) lds[s * kLanes + lane] = gs[(size_t)s * ROW];
     __syncthreads();
 
     Geo g;
@@ -1046,13 +1056,13 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         int32_t *qstate = reinterpret_cast<int32_t *>(lds);
         int32_t *qxch = reinterpret_cast<int32_t *>(xch);
         MasterQ28 m;
-        m.lpL = (int32_t)gs[(sm.xfeed + 0) * kLanes]; m.lpR = (int32_t)gs[(sm.xfeed + 1) * kLanes];
-        m.apL = (int32_t)gs[(sm.xfeed + 2) * kLanes]; m.apR = (int32_t)gs[(sm.xfeed + 3) * kLanes];
-        m.env_l = (int32_t)gs[(sm.lev + 0) * kLanes]; m.env_r = (int32_t)gs[(sm.lev + 1) * kLanes];
-        m.gsm_db = as_f(gs[(sm.lev + 2) * kLanes]); m.g_cur = (int32_t)gs[(sm.lev + 3) * kLanes]; m.g_prev = (int32_t)gs[(sm.lev + 4) * kLanes];
-        m.rp1 = m.rp2 = gs[sm.ring_pos * kLanes] & (kRingLen - 1);
+        m.lpL = (int32_t)gs[(sm.xfeed + 0) * ROW]; m.lpR = (int32_t)gs[(sm.xfeed + 1) * ROW];
+        m.apL = (int32_t)gs[(sm.xfeed + 2) * ROW]; m.apR = (int32_t)gs[(sm.xfeed + 3) * ROW];
+        m.env_l = (int32_t)gs[(sm.lev + 0) * ROW]; m.env_r = (int32_t)gs[(sm.lev + 1) * ROW];
+        m.gsm_db = as_f(gs[(sm.lev + 2) * ROW]); m.g_cur = (int32_t)gs[(sm.lev + 3) * ROW]; m.g_prev = (int32_t)gs[(sm.lev + 4) * ROW];
+        m.rp1 = m.rp2 = gs[sm.ring_pos * ROW] & (kRingLen - 1);
         m.p2_base = 1 << 28; m.p2_D = m.p2_R = m.p2_acc = m.p2_carry = 0; m.pk_l = m.pk_r = 0;
-        m.clip = gs[(sm.clip + 0) * kLanes];
+        m.clip = gs[(sm.clip + 0) * ROW];
         uint32_t k1 = 0, c1 = 0, kq = 0, cq = 0;
         for (uint32_t st = 0; st < g.steps; ++st) {
             const bool do_p1 = st < g.items;
@@ -1063,12 +1073,12 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
             lds_barrier();
         }
-        gs[(sm.xfeed + 0) * kLanes] = (uint32_t)m.lpL; gs[(sm.xfeed + 1) * kLanes] = (uint32_t)m.lpR;
-        gs[(sm.xfeed + 2) * kLanes] = (uint32_t)m.apL; gs[(sm.xfeed + 3) * kLanes] = (uint32_t)m.apR;
-        gs[(sm.lev + 0) * kLanes] = (uint32_t)m.env_l; gs[(sm.lev + 1) * kLanes] = (uint32_t)m.env_r;
-        gs[(sm.lev + 2) * kLanes] = as_u(m.gsm_db); gs[(sm.lev + 3) * kLanes] = (uint32_t)m.g_cur; gs[(sm.lev + 4) * kLanes] = (uint32_t)m.g_prev;
-        gs[sm.ring_pos * kLanes] = m.rp1;
-        gs[(sm.clip + 0) * kLanes] = m.clip;
+        gs[(sm.xfeed + 0) * ROW] = (uint32_t)m.lpL; gs[(sm.xfeed + 1) * ROW] = (uint32_t)m.lpR;
+        gs[(sm.xfeed + 2) * ROW] = (uint32_t)m.apL; gs[(sm.xfeed + 3) * ROW] = (uint32_t)m.apR;
+        gs[(sm.lev + 0) * ROW] = (uint32_t)m.env_l; gs[(sm.lev + 1) * ROW] = (uint32_t)m.env_r;
+        gs[(sm.lev + 2) * ROW] = as_u(m.gsm_db); gs[(sm.lev + 3) * ROW] = (uint32_t)m.g_cur; gs[(sm.lev + 4) * ROW] = (uint32_t)m.g_prev;
+        gs[sm.ring_pos * ROW] = m.rp1;
+        gs[(sm.clip + 0) * ROW] = m.clip;
     } else if (FLAVOR == 0) {
         int32_t *qstate = reinterpret_cast<int32_t *>(lds);
         int32_t *qpk = reinterpret_cast<int32_t *>(lds_pk);
@@ -1077,10 +1087,10 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         const int o_first = (wave - 1) * 2;
         const int o_count = (wave <= sm.n_pairs) ? 2 : 1;
         OutQ28 s;
-        s.widx = gs[sm.widx * kLanes];
-        s.loading = gs[(sm.mute + 0) * kLanes]; s.counter = gs[(sm.mute + 1) * kLanes]; s.smooth = as_f(gs[(sm.mute + 2) * kLanes]);
+        s.widx = gs[sm.widx * ROW];
+        s.loading = gs[(sm.mute + 0) * ROW]; s.counter = gs[(sm.mute + 1) * ROW]; s.smooth = as_f(gs[(sm.mute + 2) * ROW]);
         s.vmm = 0;
-        s.clip = gs[(sm.clip + wave) * kLanes];
+        s.clip = gs[(sm.clip + wave) * ROW];
         uint32_t kq = 0, cq = 0;
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (st >= g.lag + 1) {
@@ -1091,22 +1101,22 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             lds_barrier();
         }
         if (wave == 1) {
-            gs[sm.widx * kLanes] = s.widx;
-            gs[(sm.mute + 0) * kLanes] = s.loading; gs[(sm.mute + 1) * kLanes] = s.counter; gs[(sm.mute + 2) * kLanes] = as_u(s.smooth);
+            gs[sm.widx * ROW] = s.widx;
+            gs[(sm.mute + 0) * ROW] = s.loading; gs[(sm.mute + 1) * ROW] = s.counter; gs[(sm.mute + 2) * ROW] = as_u(s.smooth);
         }
-        gs[(sm.clip + wave) * kLanes] = s.clip;
+        gs[(sm.clip + wave) * ROW] = s.clip;
     } else if (wave == 0) {
         MasterF32 m;
-        m.lpL = as_f(gs[(sm.xfeed + 0) * kLanes]); m.lpR = as_f(gs[(sm.xfeed + 1) * kLanes]);
-        m.apL = as_f(gs[(sm.xfeed + 2) * kLanes]); m.apR = as_f(gs[(sm.xfeed + 3) * kLanes]);
-        m.env_l = as_f(gs[(sm.lev + 0) * kLanes]); m.env_r = as_f(gs[(sm.lev + 1) * kLanes]);
-        m.gsm_db = as_f(gs[(sm.lev + 2) * kLanes]); m.g_cur = as_f(gs[(sm.lev + 3) * kLanes]); m.g_prev = as_f(gs[(sm.lev + 4) * kLanes]);
-        m.rp1 = m.rp2 = gs[sm.ring_pos * kLanes] & (kRingLen - 1);
+        m.lpL = as_f(gs[(sm.xfeed + 0) * ROW]); m.lpR = as_f(gs[(sm.xfeed + 1) * ROW]);
+        m.apL = as_f(gs[(sm.xfeed + 2) * ROW]); m.apR = as_f(gs[(sm.xfeed + 3) * ROW]);
+        m.env_l = as_f(gs[(sm.lev + 0) * ROW]); m.env_r = as_f(gs[(sm.lev + 1) * ROW]);
+        m.gsm_db = as_f(gs[(sm.lev + 2) * ROW]); m.g_cur = as_f(gs[(sm.lev + 3) * ROW]); m.g_prev = as_f(gs[(sm.lev + 4) * ROW]);
+        m.rp1 = m.rp2 = gs[sm.ring_pos * ROW] & (kRingLen - 1);
         m.p2_gain = 1.0f; m.p2_step = 0.0f; m.pk_l = m.pk_r = 0.0f;
         m.pre_valid = 0;
 #pragma unroll
         for (int v = 0; v < T / 4; ++v) m.pre[v] = u32x4{0, 0, 0, 0};
-        m.clip = gs[(sm.clip + 0) * kLanes];
+        m.clip = gs[(sm.clip + 0) * ROW];
         uint32_t k1 = 0, c1 = 0, kq = 0, cq = 0;
         WT_DECL;
         for (uint32_t st = 0; st < g.steps; ++st) {
@@ -1114,7 +1124,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             const bool do_item = st >= g.lag && st < g.items + g.lag;
             const uint32_t q = st - g.lag;
             if (do_p1 || do_item) {
-                master_step_f32<TAIL>(a, img, sm, g, m, lds_state, xch, wg, lane, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
+                master_step_f32<TAIL>(a, img, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
             }
             if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
             if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
@@ -1124,12 +1134,12 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         }
         WT_FINISH(0);
         if (active) {
-            gs[(sm.xfeed + 0) * kLanes] = as_u(m.lpL); gs[(sm.xfeed + 1) * kLanes] = as_u(m.lpR);
-            gs[(sm.xfeed + 2) * kLanes] = as_u(m.apL); gs[(sm.xfeed + 3) * kLanes] = as_u(m.apR);
-            gs[(sm.lev + 0) * kLanes] = as_u(m.env_l); gs[(sm.lev + 1) * kLanes] = as_u(m.env_r);
-            gs[(sm.lev + 2) * kLanes] = as_u(m.gsm_db); gs[(sm.lev + 3) * kLanes] = as_u(m.g_cur); gs[(sm.lev + 4) * kLanes] = as_u(m.g_prev);
-            gs[sm.ring_pos * kLanes] = m.rp1;
-            gs[(sm.clip + 0) * kLanes] = m.clip;
+            gs[(sm.xfeed + 0) * ROW] = as_u(m.lpL); gs[(sm.xfeed + 1) * ROW] = as_u(m.lpR);
+            gs[(sm.xfeed + 2) * ROW] = as_u(m.apL); gs[(sm.xfeed + 3) * ROW] = as_u(m.apR);
+            gs[(sm.lev + 0) * ROW] = as_u(m.env_l); gs[(sm.lev + 1) * ROW] = as_u(m.env_r);
+            gs[(sm.lev + 2) * ROW] = as_u(m.gsm_db); gs[(sm.lev + 3) * ROW] = as_u(m.g_cur); gs[(sm.lev + 4) * ROW] = as_u(m.g_prev);
+            gs[sm.ring_pos * ROW] = m.rp1;
+            gs[(sm.clip + 0) * ROW] = m.clip;
         }
     } else {
         // outputs split 3/3/3 (float) or 2/2/1 (Q28) over waves 1..3
@@ -1139,16 +1149,16 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         if (o_count > per) o_count = per;
         if (o_count < 0) o_count = 0;
         OutF32 s;
-        s.widx = gs[sm.widx * kLanes];
-        s.loading = gs[(sm.mute + 0) * kLanes]; s.counter = gs[(sm.mute + 1) * kLanes]; s.smooth = as_f(gs[(sm.mute + 2) * kLanes]);
+        s.widx = gs[sm.widx * ROW];
+        s.loading = gs[(sm.mute + 0) * ROW]; s.counter = gs[(sm.mute + 1) * ROW]; s.smooth = as_f(gs[(sm.mute + 2) * ROW]);
         s.vmm = 0.0f;
-        s.clip = gs[(sm.clip + wave) * kLanes];
+        s.clip = gs[(sm.clip + wave) * ROW];
         uint32_t kq = 0, cq = 0;
         WT_DECL;
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
-                output_item_f32<TAIL>(a, img, sm, g, s, lds_state, lds_pk, xch, wg, lane, stream, active, o_first, o_count, kq, cq, q);
+                output_item_f32<TAIL>(a, img, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
             WT_BEFORE_BARRIER;
@@ -1158,15 +1168,15 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         WT_FINISH(wave);
         if (active) {
             if (wave == 1) {
-                gs[sm.widx * kLanes] = s.widx;
-                gs[(sm.mute + 0) * kLanes] = s.loading; gs[(sm.mute + 1) * kLanes] = s.counter; gs[(sm.mute + 2) * kLanes] = as_u(s.smooth);
+                gs[sm.widx * ROW] = s.widx;
+                gs[(sm.mute + 0) * ROW] = s.loading; gs[(sm.mute + 1) * ROW] = s.counter; gs[(sm.mute + 2) * ROW] = as_u(s.smooth);
             }
-            gs[(sm.clip + wave) * kLanes] = s.clip;
+            gs[(sm.clip + wave) * ROW] = s.clip;
         }
     }
     __syncthreads();
     if (active)
-        for (int s = wave; s < sm.lds_slots; s += 4) gs[(size_t)s * kLanes] = lds[s * kLanes + lane];
+        for (int s = wave; s < sm.lds_slots; s += 4) gs[(size_t)s * ROW] = lds[s * kLanes + lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1175,37 +1185,41 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
 template <int FLAVOR>
 __global__ void state_ops_kernel(const WgItem *items, StateOps ops, uint32_t *state, uint32_t *dlines, uint32_t *ring, uint32_t n_streams) {
     constexpr StateMap sm = make_state_map(FLAVOR);
+    constexpr uint32_t ROW = sm.row;
     const WgItem item = items[blockIdx.x];
-    const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6, parts = blockDim.x >> 6;
-    const uint32_t stream = item.wg * kLanes + lane;
-    if (!(((item.mask >> lane) & 1ull) && stream < n_streams)) return;
-    uint32_t *gs = state + (size_t)item.wg * sm.n_slots * kLanes + lane;
+    // one thread column per stream of the workgroup (64 or 128), `parts` row-slices for the bulk zeroing
+    const uint32_t col = threadIdx.x % ROW, part = threadIdx.x / ROW, parts = blockDim.x / ROW;
+    const uint32_t lane = FLAVOR ? col >> 1 : col;
+    const uint64_t m = (FLAVOR && (col & 1u)) ? item.mask1 : item.mask;
+    const uint32_t stream = item.wg * ROW + col;
+    if (!(((m >> lane) & 1ull) && stream < n_streams)) return;
+    uint32_t *gs = state + (size_t)item.wg * sm.n_slots * ROW + col;
     if (part == 0) {
         for (int ch = 0; ch < sm.n_ch; ++ch)
             for (int b = 0; b < kBands; ++b)
                 if (ops.reset_all_eq || ((ops.reset_band[ch] >> b) & 1u)) {
-                    gs[(size_t)(sm.eq + (ch * kBands + b) * 2) * kLanes] = 0;
-                    gs[(size_t)(sm.eq + (ch * kBands + b) * 2 + 1) * kLanes] = 0;
+                    gs[(size_t)(sm.eq + (ch * kBands + b) * 2) * ROW] = 0;
+                    gs[(size_t)(sm.eq + (ch * kBands + b) * 2 + 1) * ROW] = 0;
                 }
-        if (ops.reset_crossfeed) for (int i = 0; i < 4; ++i) gs[(size_t)(sm.xfeed + i) * kLanes] = 0;
+        if (ops.reset_crossfeed) for (int i = 0; i < 4; ++i) gs[(size_t)(sm.xfeed + i) * ROW] = 0;
         if (ops.reset_leveller) {   // leveller_reset_state: zero everything, unity gains
             const uint32_t unity = FLAVOR ? 0x3f800000u : (1u << 28);
-            gs[(size_t)(sm.lev + 0) * kLanes] = 0; gs[(size_t)(sm.lev + 1) * kLanes] = 0; gs[(size_t)(sm.lev + 2) * kLanes] = 0;
-            gs[(size_t)(sm.lev + 3) * kLanes] = unity; gs[(size_t)(sm.lev + 4) * kLanes] = unity;
-            gs[(size_t)sm.ring_pos * kLanes] = 0;
+            gs[(size_t)(sm.lev + 0) * ROW] = 0; gs[(size_t)(sm.lev + 1) * ROW] = 0; gs[(size_t)(sm.lev + 2) * ROW] = 0;
+            gs[(size_t)(sm.lev + 3) * ROW] = unity; gs[(size_t)(sm.lev + 4) * ROW] = unity;
+            gs[(size_t)sm.ring_pos * ROW] = 0;
         }
-        if (ops.mute_start) { gs[(size_t)(sm.mute + 0) * kLanes] = 1; gs[(size_t)(sm.mute + 1) * kLanes] = ops.mute_samples; }
-        if (ops.mute_cancel) gs[(size_t)(sm.mute + 0) * kLanes] = 0;
-        if (ops.clear_clips) for (int i = 0; i < 4; ++i) gs[(size_t)(sm.clip + i) * kLanes] = 0;
+        if (ops.mute_start) { gs[(size_t)(sm.mute + 0) * ROW] = 1; gs[(size_t)(sm.mute + 1) * ROW] = ops.mute_samples; }
+        if (ops.mute_cancel) gs[(size_t)(sm.mute + 0) * ROW] = 0;
+        if (ops.clear_clips) for (int i = 0; i < 4; ++i) gs[(size_t)(sm.clip + i) * ROW] = 0;
     }
     if (ops.reset_leveller) {
-        uint32_t *r = ring + (size_t)item.wg * kRingLen * 2 * kLanes + lane;
-        for (uint32_t p = part; p < (uint32_t)kRingLen * 2; p += parts) r[(size_t)p * kLanes] = 0;
+        uint32_t *r = ring + (size_t)item.wg * kRingLen * 2 * ROW + col;
+        for (uint32_t p = part; p < (uint32_t)kRingLen * 2; p += parts) r[(size_t)p * ROW] = 0;
     }
     if (ops.zero_delay_lines) {
-        uint32_t *d = dlines + (size_t)item.wg * sm.n_out * (size_t)sm.max_delay * kLanes + lane;
+        uint32_t *d = dlines + (size_t)item.wg * sm.n_out * (size_t)sm.max_delay * ROW + col;
         const uint32_t total = (uint32_t)sm.n_out * (uint32_t)sm.max_delay;
-        for (uint32_t p = part; p < total; p += parts) d[(size_t)p * kLanes] = 0;
+        for (uint32_t p = part; p < total; p += parts) d[(size_t)p * ROW] = 0;
     }
 }
 
@@ -1213,13 +1227,14 @@ __global__ void state_ops_kernel(const WgItem *items, StateOps ops, uint32_t *st
 template <int FLAVOR>
 __global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
     constexpr StateMap sm = make_state_map(FLAVOR);
-    const uint32_t wg = blockIdx.x, lane = threadIdx.x;
-    if (wg >= n_wg) return;
-    uint32_t *gs = state + (size_t)wg * sm.n_slots * kLanes + lane;
+    constexpr uint32_t ROW = sm.row;
+    const uint32_t wg = blockIdx.x, col = threadIdx.x;
+    if (wg >= n_wg || col >= ROW) return;
+    uint32_t *gs = state + (size_t)wg * sm.n_slots * ROW + col;
     const uint32_t unity = FLAVOR ? 0x3f800000u : (1u << 28);
-    gs[(size_t)(sm.lev + 3) * kLanes] = unity;
-    gs[(size_t)(sm.lev + 4) * kLanes] = unity;
-    gs[(size_t)(sm.mute + 2) * kLanes] = 0x3f800000u;   // preset_mute_smooth_gain = 1.0f (usb_audio.c:457)
+    gs[(size_t)(sm.lev + 3) * ROW] = unity;
+    gs[(size_t)(sm.lev + 4) * ROW] = unity;
+    gs[(size_t)(sm.mute + 2) * ROW] = 0x3f800000u;   // preset_mute_smooth_gain = 1.0f (usb_audio.c:457)
 }
 
 }  // namespace
@@ -1247,8 +1262,14 @@ static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_chain(int flavor, const KArgs &args, uint32_t n_items, hipStream_t stream) {
-    return flavor ? launch_chain_t<1>(args, n_items, stream) : launch_chain_t<0>(args, n_items, stream);
+hipError_t launch_chain(int flavor, int packed, const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    if (!flavor) return launch_chain_t<0>(args, n_items, stream);
+    if (!packed) return launch_chain_t<1>(args, n_items, stream);
+    // packed kernel not built yet: run the lane pairs through the scalar kernel, one component at a time
+    KArgs a0 = args, a1 = args;
+    a0.comp = 0; a1.comp = 1;
+    hipError_t e = launch_chain_t<1>(a0, n_items, stream);
+    return e != hipSuccess ? e : launch_chain_t<1>(a1, n_items, stream);
 }
 
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
@@ -1259,8 +1280,8 @@ hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, c
 }
 
 hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream) {
-    if (flavor) hipLaunchKernelGGL(state_init_kernel<1>, dim3(n_wg), dim3(kLanes), 0, stream, state, n_wg);
-    else hipLaunchKernelGGL(state_init_kernel<0>, dim3(n_wg), dim3(kLanes), 0, stream, state, n_wg);
+    if (flavor) hipLaunchKernelGGL(state_init_kernel<1>, dim3(n_wg), dim3(128), 0, stream, state, n_wg);
+    else hipLaunchKernelGGL(state_init_kernel<0>, dim3(n_wg), dim3(64), 0, stream, state, n_wg);
     return hipGetLastError();
 }
 
