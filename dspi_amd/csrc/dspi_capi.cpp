@@ -39,6 +39,7 @@ struct dspi_ctx {
     hipStream_t hs = nullptr;
     uint32_t *d_state = nullptr, *d_dlines = nullptr, *d_ring = nullptr;
     DevImage *d_images = nullptr;
+    std::vector<uint32_t> image_flags;             // DevImage::flags of each uploaded image (kernel variant selection)
     size_t d_images_cap = 0;
     WgItem *d_items = nullptr;
     size_t d_items_cap = 0;
@@ -176,6 +177,8 @@ int commit_params(dspi_ctx *c) {
         if (p.dirty) {
             DevImage img;
             p.build_image(img);
+            if (c->image_flags.size() <= i) c->image_flags.resize(i + 1, 0u);
+            c->image_flags[i] = img.flags;
             HIPCK(c, hipMemcpy(c->d_images + i, &img, sizeof(img), hipMemcpyHostToDevice));   // synchronous: `img` is a local
             p.dirty = false;
         }
@@ -414,7 +417,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
             if (items.empty()) continue;
             a.items = c->d_items + c->image_item_offset[ls[l].list][i];
             a.comp = ls[l].comp;
-            hipError_t e = launch_chain(c->flavor, ls[l].packed, a, (uint32_t)items.size(), c->hs);
+            hipError_t e = launch_chain(c->flavor, ls[l].packed, (c->image_flags[i] & IF_LEVELLER_ON) != 0, a, (uint32_t)items.size(), c->hs);
             if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
             if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));
         }

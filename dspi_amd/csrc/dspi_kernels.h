@@ -23,10 +23,11 @@ struct KArgs {
     uint32_t comp;           // float flavour, scalar kernel: which of a lane's two streams (column = lane*2 + comp)
 };
 
-size_t chain_lds_bytes(int flavor);
+size_t chain_lds_bytes(int flavor, int packed);
 // packed != 0 (float flavour only): items list lanes whose two streams are both processed (v_pk kernel);
 // packed == 0: scalar kernel, one stream per lane (float: the stream args.comp of each listed lane)
-hipError_t launch_chain(int flavor, int packed, const KArgs &args, uint32_t n_items, hipStream_t stream);
+// leveller_on: IF_LEVELLER_ON of args.img (the host knows it; the packed kernel is specialised on it)
+hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
                             uint32_t *ring, uint32_t n_streams, hipStream_t stream);
 hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream);

@@ -21,6 +21,7 @@
 // line, so the master wave never holds more than one chunk in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dspi_detmath.h"
 #include "dspi_image.h"
@@ -190,7 +191,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 #ifdef DSPI_WAVE_TIMING
 // development aid: per-wave busy cycles (outside the barrier) and total cycles, summed over workgroups
-__device__ unsigned long long g_wave_timing[8];
+__device__ unsigned long long g_wave_timing[16];
 #define WT_DECL unsigned long long wt_busy = 0, wt_t0 = __builtin_amdgcn_s_memtime(), wt_start = wt_t0
 #define WT_BEFORE_BARRIER wt_busy += __builtin_amdgcn_s_memtime() - wt_t0
 #define WT_AFTER_BARRIER wt_t0 = __builtin_amdgcn_s_memtime()
@@ -1012,8 +1013,10 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
     if (cq == g.cpb - 1 && (flags & IF_ANY_DELAY)) s.widx = (s.widx + g.B) & ((uint32_t)sm.max_delay - 1u);
 }
 
+#include "dspi_chain_pk.inc"
+
 // ==========================================================================================
-// the kernel
+// the one-stream-per-lane kernel (Q28 flavour; float flavour: lanes whose two streams differ in image)
 // ==========================================================================================
 template <int FLAVOR, bool TAIL>
 __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
@@ -1242,14 +1245,14 @@ __global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
-size_t chain_lds_bytes(int flavor) {
+size_t chain_lds_bytes(int flavor, int packed) {
     const StateMap sm = make_state_map(flavor);
-    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T) * kLanes * sizeof(uint32_t);
+    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t);
 }
 
 template <int FLAVOR>
 static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
-    const size_t lds = chain_lds_bytes(FLAVOR);
+    const size_t lds = chain_lds_bytes(FLAVOR, 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1262,14 +1265,43 @@ static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_chain(int flavor, int packed, const KArgs &args, uint32_t n_items, hipStream_t stream) {
+template <bool TAIL, bool LEV, bool PCM24>
+static hipError_t launch_chain_pk_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    const size_t lds = chain_lds_bytes(1, 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
+    return hipGetLastError();
+}
+
+static hipError_t launch_chain_pk(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream) {
+    const int v = ((args.block_len % T) ? 4 : 0) | (leveller_on ? 2 : 0) | (args.bit_depth == 24 ? 1 : 0);
+    switch (v) {
+        case 0: return launch_chain_pk_t<false, false, false>(args, n_items, stream);
+        case 1: return launch_chain_pk_t<false, false, true>(args, n_items, stream);
+        case 2: return launch_chain_pk_t<false, true, false>(args, n_items, stream);
+        case 3: return launch_chain_pk_t<false, true, true>(args, n_items, stream);
+        case 4: return launch_chain_pk_t<true, false, false>(args, n_items, stream);
+        case 5: return launch_chain_pk_t<true, false, true>(args, n_items, stream);
+        case 6: return launch_chain_pk_t<true, true, false>(args, n_items, stream);
+        default: return launch_chain_pk_t<true, true, true>(args, n_items, stream);
+    }
+}
+
+hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream) {
     if (!flavor) return launch_chain_t<0>(args, n_items, stream);
     if (!packed) return launch_chain_t<1>(args, n_items, stream);
-    // packed kernel not built yet: run the lane pairs through the scalar kernel, one component at a time
-    KArgs a0 = args, a1 = args;
-    a0.comp = 0; a1.comp = 1;
-    hipError_t e = launch_chain_t<1>(a0, n_items, stream);
-    return e != hipSuccess ? e : launch_chain_t<1>(a1, n_items, stream);
+    if (getenv("DSPI_NO_PACKED")) {      // development switch: lane pairs through the one-stream kernel, one component at a time
+        KArgs a0 = args, a1 = args;
+        a0.comp = 0; a1.comp = 1;
+        hipError_t e = launch_chain_t<1>(a0, n_items, stream);
+        return e != hipSuccess ? e : launch_chain_t<1>(a1, n_items, stream);
+    }
+    return launch_chain_pk(args, leveller_on, n_items, stream);
 }
 
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
@@ -1286,10 +1318,10 @@ hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStre
 }
 
 #ifdef DSPI_WAVE_TIMING
-extern "C" int dspi_debug_wave_timing(unsigned long long *out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wave_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+extern "C" int dspi_debug_wave_timing(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wave_timing), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_timing), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

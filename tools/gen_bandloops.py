@@ -2,68 +2,183 @@
 """Generates dspi_amd/csrc/dspi_bandloops.inc: the hand-scheduled gfx950 EQ band loops (inline asm).
 
 Each function runs ONE band over a 16-sample chunk, in place on tied VGPRs ("+v"), with the coefficients as
-SGPR operands.  One v_mul/v_add/v_sub per operation of the reference loops (firmware/DSPi/dsp_pipeline.c:298-362),
-in the reference's association order, so the results are bit-identical to the C code compiled without contraction.
+SGPR operands.  One multiply / add / subtract per operation of the reference loops
+(firmware/DSPi/dsp_pipeline.c:298-362), in the reference's association order, so the results are bit-identical
+to the C code compiled without contraction.
 
-Why asm: hipcc's phi/copy handling around the five-way kind switch cost ~48 v_mov per band visit, and a wave
-can only issue one instruction every ~4.3 cycles (tools/probe/probe2), so every copy is a lost VALU slot.
+Two families:
+  band16_*     one stream per lane  (v_mul_f32 / v_add_f32 / v_sub_f32)          — Q28-free scalar float kernel
+  band16pk_*   two streams per lane (v_pk_mul_f32 / v_pk_add_f32, VOP3P)         — the packed float kernel
+               coefficients arrive as the three aligned SGPR pairs {c0,c1} {c2,c3} {c4,c5} straight from the
+               s_load of a DevBand; op_sel picks the half and broadcasts it to both streams.  a - b is emitted as
+               v_pk_add_f32 a, -b (neg_lo/neg_hi), which is the same IEEE operation.
+
+Why asm: hipcc's phi/copy handling around the five-way kind switch cost ~48 v_mov per band visit, and a SIMD
+issues one VALU instruction per ~4.1 cycles whatever the occupancy (tools/probe/probe3), so every copy is a lost
+slot.  The packed family is additionally list-scheduled: a dependent v_pk op can only issue ~9 cycles after its
+producer (tools/probe/probe4), so independent work of the following samples is interleaved into the recurrences.
 """
 import os
 
 T = 16
 
-
+# ---------------------------------------------------------------------------------------------------------
+# operation lists: (op, dst, a, b) with op in mul/add/sub/mov; operands: 'x' (sample, in place), 's1','s2',
+# 'c0'..'c5', temps 't0'..'t3'
+# ---------------------------------------------------------------------------------------------------------
 def ops(kind):
     if kind == 'BQ':   # TDF2 biquad
-        return ["v_mul_f32 %[t0], %[c0], {x}",      # b0*in
-                "v_mul_f32 %[t1], %[c1], {x}",      # b1*in
-                "v_mul_f32 %[t2], %[c2], {x}",      # b2*in
-                "v_add_f32 {x}, %[t0], %[s1]",      # y = b0*in + s1
-                "v_mul_f32 %[t0], %[c3], {x}",      # a1*y
-                "v_mul_f32 %[t3], %[c4], {x}",      # a2*y
-                "v_sub_f32 %[t1], %[t1], %[t0]",    # b1*in - a1*y
-                "v_add_f32 %[s1], %[t1], %[s2]",    # ... + s2
-                "v_sub_f32 %[s2], %[t2], %[t3]"]    # b2*in - a2*y
-    core = ["v_sub_f32 %[t0], {x}, %[s2]",          # v3 = in - ic2eq
-            "v_mul_f32 %[t1], %[c0], %[s1]",        # a1*ic1eq
-            "v_mul_f32 %[t2], %[c1], %[t0]",        # a2*v3
-            "v_add_f32 %[t1], %[t1], %[t2]",        # v1
-            "v_mul_f32 %[t2], %[c1], %[s1]",        # a2*ic1eq
-            "v_add_f32 %[t2], %[s2], %[t2]",        # ic2eq + a2*ic1eq
-            "v_mul_f32 %[t0], %[c2], %[t0]",        # a3*v3
-            "v_add_f32 %[t2], %[t2], %[t0]",        # v2
-            "v_add_f32 %[t0], %[t1], %[t1]",        # 2*v1 (exact)
-            "v_sub_f32 %[s1], %[t0], %[s1]",        # ic1eq = 2 v1 - ic1eq
-            "v_add_f32 %[t0], %[t2], %[t2]",        # 2*v2
-            "v_sub_f32 %[s2], %[t0], %[s2]"]        # ic2eq = 2 v2 - ic2eq
+        return [('mul', 't0', 'c0', 'x'),      # b0*in
+                ('mul', 't1', 'c1', 'x'),      # b1*in
+                ('mul', 't2', 'c2', 'x'),      # b2*in
+                ('add', 'x', 't0', 's1'),      # y = b0*in + s1
+                ('mul', 't0', 'c3', 'x'),      # a1*y
+                ('mul', 't3', 'c4', 'x'),      # a2*y
+                ('sub', 't1', 't1', 't0'),     # b1*in - a1*y
+                ('add', 's1', 't1', 's2'),     # ... + s2
+                ('sub', 's2', 't2', 't3')]     # b2*in - a2*y
+    v2 = 'x' if kind == 'LP' else 't2'         # low-pass: the output IS v2, form it in place (no copy)
+    core = [('sub', 't0', 'x', 's2'),          # v3 = in - ic2eq
+            ('mul', 't1', 'c0', 's1'),         # a1*ic1eq
+            ('mul', 't2', 'c1', 't0'),         # a2*v3
+            ('add', 't1', 't1', 't2'),         # v1
+            ('mul', 't2', 'c1', 's1'),         # a2*ic1eq
+            ('add', 't2', 's2', 't2'),         # ic2eq + a2*ic1eq
+            ('mul', 't0', 'c2', 't0'),         # a3*v3
+            ('add', v2, 't2', 't0'),           # v2
+            ('add', 't0', 't1', 't1'),         # 2*v1 (exact)
+            ('sub', 's1', 't0', 's1'),         # ic1eq = 2 v1 - ic1eq
+            ('add', 't0', v2, v2),             # 2*v2
+            ('sub', 's2', 't0', 's2')]         # ic2eq = 2 v2 - ic2eq
     if kind == 'LP':
-        return core + ["v_mov_b32 {x}, %[t2]"]
+        return core
     if kind == 'HP':
-        return core + ["v_mul_f32 %[t0], %[c3], %[t1]", "v_add_f32 {x}, {x}, %[t0]", "v_sub_f32 {x}, {x}, %[t2]"]
+        return core + [('mul', 't0', 'c3', 't1'), ('add', 'x', 'x', 't0'), ('sub', 'x', 'x', 't2')]
     if kind == 'PK':
-        return core + ["v_mul_f32 %[t0], %[c3], %[t1]", "v_add_f32 {x}, {x}, %[t0]"]
+        return core + [('mul', 't0', 'c3', 't1'), ('add', 'x', 'x', 't0')]
     if kind == 'SH':
-        return core + ["v_mul_f32 %[t0], %[c3], {x}", "v_mul_f32 %[t1], %[c4], %[t1]", "v_add_f32 %[t0], %[t0], %[t1]",
-                       "v_mul_f32 %[t2], %[c5], %[t2]", "v_add_f32 {x}, %[t0], %[t2]"]
+        return core + [('mul', 't0', 'c3', 'x'), ('mul', 't1', 'c4', 't1'), ('add', 't0', 't0', 't1'),
+                       ('mul', 't2', 'c5', 't2'), ('add', 'x', 't0', 't2')]
     raise ValueError(kind)
 
 
-def block(kind):
-    lines = []
+# ---------------------------------------------------------------------------------------------------------
+# scalar family: straight program order (a dependent non-packed op issues back to back)
+# ---------------------------------------------------------------------------------------------------------
+def scalar_line(op, d, a, b, i, tset=0):
+    def r(n):
+        return '%%[x%d]' % i if n == 'x' else '%%[%s]' % n
+    return "v_%s_f32 %s, %s, %s" % (op, r(d), r(a), r(b))
+
+
+def block_scalar(kind):
+    return [scalar_line(*o, i) for i in range(T) for o in ops(kind)]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# packed family: list scheduling over the whole 16-sample block
+# ---------------------------------------------------------------------------------------------------------
+NTSETS = 3          # rotating temp sets; sample i uses set i % NTSETS
+LAT_SLOTS = 3       # a dependent packed op wants >= 3 issue slots (12 cycles) after its producer
+
+
+def pk_operand(n, i):
+    if n == 'x':
+        return '%%[x%d]' % i, ''
+    if n in ('s1', 's2'):
+        return '%%[%s]' % n, ''
+    if n[0] == 't':
+        return '%%[t%d_%s]' % (i % NTSETS, n[1]), ''
+    c = int(n[1])
+    return '%%[c%d%d]' % (c & ~1, c | 1), ('lo' if c % 2 == 0 else 'hi')
+
+
+def pk_line(op, d, a, b, i):
+    dn, _ = pk_operand(d, i)
+    an, asel = pk_operand(a, i)
+    bn, bsel = pk_operand(b, i)
+    assert not bsel, "coefficients are always the first source"
+    mods = ''
+    if asel == 'lo':
+        mods += ' op_sel_hi:[0,1]'
+    elif asel == 'hi':
+        mods += ' op_sel:[1,0]'
+    if op == 'sub':
+        mods += ' neg_lo:[0,1] neg_hi:[0,1]'
+    return "v_pk_%s_f32 %s, %s, %s%s" % ('mul' if op == 'mul' else 'add', dn, an, bn, mods)
+
+
+def block_pk(kind):
+    # instances with concrete register names for hazard analysis
+    inst = []
     for i in range(T):
-        lines += [o.replace('{x}', '%%[x%d]' % i) for o in ops(kind)]
-    return lines
+        for (op, d, a, b) in ops(kind):
+            def phys(n):
+                if n == 'x':
+                    return 'x%d' % i
+                if n[0] == 't':
+                    return 't%d_%s' % (i % NTSETS, n[1])
+                return n
+            inst.append(dict(text=pk_line(op, d, a, b, i), w=phys(d), r=[phys(a), phys(b)]))
+    n = len(inst)
+    preds = [set() for _ in range(n)]      # (j, is_raw)
+    last_w = {}
+    readers = {}
+    for k, it in enumerate(inst):
+        for rr in it['r']:
+            if rr in last_w:
+                preds[k].add((last_w[rr], True))
+        if it['w'] in last_w:
+            preds[k].add((last_w[it['w']], False))
+        for j in readers.get(it['w'], []):
+            if j != k:
+                preds[k].add((j, False))
+        last_w[it['w']] = k
+        readers[it['w']] = []
+        for rr in it['r']:
+            readers.setdefault(rr, []).append(k)
+    succs = [[] for _ in range(n)]
+    for k in range(n):
+        for (j, raw) in preds[k]:
+            succs[j].append((k, raw))
+    # critical path (in slots) to the end of the block
+    cp = [0] * n
+    for k in range(n - 1, -1, -1):
+        cp[k] = 1 + max([cp[s] + (LAT_SLOTS - 1 if raw else 0) for (s, raw) in succs[k]] or [0])
+    done_slot = {}
+    order = []
+    slot = 0
+    remaining = set(range(n))
+    while remaining:
+        best = None
+        for k in sorted(remaining):
+            if any(j not in done_slot for (j, _) in preds[k]):
+                continue
+            est = max([done_slot[j] + (LAT_SLOTS if raw else 1) for (j, raw) in preds[k]] or [0])
+            key = (max(est, slot), -cp[k], k)
+            if best is None or key < best[0]:
+                best = (key, k)
+            if k - min(remaining) > 64:      # bounded look-ahead keeps the schedule local
+                break
+        k = best[1]
+        slot = max(best[0][0], slot)
+        done_slot[k] = slot
+        slot += 1
+        order.append(k)
+        remaining.discard(k)
+    return [inst[k]['text'] for k in order]
 
 
-def emit(name, kinds, out):
+# ---------------------------------------------------------------------------------------------------------
+def emit(name, kinds, out, packed):
     """One asm statement that dispatches on the (wave-uniform) band kind with scalar branches and runs the
     matching 16-sample loop.  Keeping the dispatch inside the asm means the compiler sees a single in-place
     update of x[0..15] — no phi copies on any path."""
+    block = block_pk if packed else block_scalar
     lines = ["s_cmp_eq_u32 %[k], 0", "s_cbranch_scc1 .Lend_%="]
     for kname, kval in kinds[:-1]:
         lines += ["s_cmp_eq_u32 %%[k], %d" % kval, "s_cbranch_scc1 .L%s_%%=" % kname]
-    # last kind is the fall-through
-    last = kinds[-1][0]
+    last = kinds[-1][0]                                  # last kind is the fall-through
     lines += block(last)
     lines += ["s_branch .Lend_%="]
     for kname, kval in kinds[:-1]:
@@ -71,10 +186,17 @@ def emit(name, kinds, out):
     lines += [".Lend_%=:"]
     body = '\n'.join('        "%s\\n\\t"' % l for l in lines)
     xs = ', '.join('[x%d] "+v"(x[%d])' % (i, i) for i in range(T))
-    ts = ', '.join('[t%d] "=&v"(t%d)' % (i, i) for i in range(4))
-    cs = ', '.join('[c%d] "s"(c%d)' % (i, i) for i in range(6))
-    out.append("__device__ __forceinline__ void %s(float (&x)[16], float &s1, float &s2, uint32_t kind, float c0, float c1, float c2, float c3, float c4, float c5) {" % name)
-    out.append("    float t0, t1, t2, t3;")
+    if packed:
+        tn = ['t%d_%d' % (s, j) for s in range(NTSETS) for j in range(4)]
+        ts = ', '.join('[%s] "=&v"(%s)' % (t, t) for t in tn)
+        cs = '[c01] "s"(c01), [c23] "s"(c23), [c45] "s"(c45)'
+        out.append("__device__ __forceinline__ void %s(v2f (&x)[16], v2f &s1, v2f &s2, uint32_t kind, v2f c01, v2f c23, v2f c45) {" % name)
+        out.append("    v2f %s;" % ', '.join(tn))
+    else:
+        ts = ', '.join('[t%d] "=&v"(t%d)' % (i, i) for i in range(4))
+        cs = ', '.join('[c%d] "s"(c%d)' % (i, i) for i in range(6))
+        out.append("__device__ __forceinline__ void %s(float (&x)[16], float &s1, float &s2, uint32_t kind, float c0, float c1, float c2, float c3, float c4, float c5) {" % name)
+        out.append("    float t0, t1, t2, t3;")
     out.append("    asm volatile(")
     out.append(body)
     out.append("        : %s, [s1] \"+v\"(s1), [s2] \"+v\"(s2), %s" % (xs, ts))
@@ -84,16 +206,24 @@ def emit(name, kinds, out):
     out.append("")
 
 
+HEADER = ["// %s — GENERATED by tools/gen_bandloops.py; do not edit by hand.",
+          "// Hand-scheduled gfx950 band loops: 16 samples of one EQ band, in place on tied VGPRs (\"+v\"), coefficients in SGPRs.",
+          "// One multiply/add/subtract per reference operation, in the reference's association order (dsp_pipeline.c:298-362).",
+          "// kind: BandKind (dspi_image.h) — 0 bypass, 1 biquad, 2 SVF low-pass, 3 SVF high-pass, 4 SVF peaking, 5 SVF shelf."]
+
+
 def main():
-    out = ["// dspi_bandloops.inc — GENERATED by tools/gen_bandloops.py; do not edit by hand.",
-           "// Hand-scheduled gfx950 band loops: 16 samples of one EQ band, in place on tied VGPRs (\"+v\"), coefficients in SGPRs.",
-           "// One v_mul/v_add/v_sub per reference operation, in the reference's association order (dsp_pipeline.c:298-362).",
-           "// kind: BandKind (dspi_image.h) — 0 bypass, 1 biquad, 2 SVF low-pass, 3 SVF high-pass, 4 SVF peaking, 5 SVF shelf.", ""]
-    emit("band16_any", [('BQ', 1), ('LP', 2), ('HP', 3), ('PK', 4), ('SH', 5)], out)
-    emit("band16_shelf", [('SH', 5)], out)      # loudness stages are shelves (or bypassed)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dspi_amd", "csrc", "dspi_bandloops.inc")
-    open(path, "w").write('\n'.join(out))
-    print("wrote", os.path.normpath(path))
+    allk = [('BQ', 1), ('LP', 2), ('HP', 3), ('PK', 4), ('SH', 5)]
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dspi_amd", "csrc")
+    for fname, packed, note in (("dspi_bandloops.inc", False, "// one stream per lane (v_mul_f32 / v_add_f32 / v_sub_f32), program order"),
+                                ("dspi_bandloops_pk.inc", True, "// two streams per lane (v_pk_mul_f32 / v_pk_add_f32), list-scheduled; needs v2f")):
+        out = [HEADER[0] % fname] + HEADER[1:] + [note, ""]
+        pre = "band16pk" if packed else "band16"
+        emit(pre + "_any", allk, out, packed)
+        emit(pre + "_shelf", [('SH', 5)], out, packed)      # loudness stages are shelves (or bypassed)
+        path = os.path.join(here, fname)
+        open(path, "w").write('\n'.join(out))
+        print("wrote", os.path.normpath(path))
 
 
 if __name__ == "__main__":
