@@ -28,17 +28,18 @@ def run(label, blob, outputs=True, steps=4):
     extra = ''
     if os.environ.get('DSPI_LIB', '').endswith('timing.so'):
         import ctypes
-        buf = (ctypes.c_ulonglong * 8)()
+        buf = (ctypes.c_ulonglong * 24)()
         d.L.dspi_debug_wave_timing(buf, 1)
-        nwg = (S + 63) // 64
-        per = [buf[i] / nwg / (steps + 1) for i in range(8)]      # cycles per workgroup per launch
-        extra = '  busy/total Mcyc per WG: ' + ' '.join(f'w{w}:{per[2*w]/1e6:.2f}/{per[2*w+1]/1e6:.2f}' for w in range(4))
+        nwg = (S + 127) // 128
+        per = [buf[i] / nwg / (steps + 1) for i in range(16)]     # cycles per workgroup per launch
+        extra = '\n      busy/total Mcyc per WG: ' + ' '.join(f'w{w}:{per[2*w]/1e6:.2f}/{per[2*w+1]/1e6:.2f}' for w in range(8)) + '  simd(wg0): ' + ' '.join(str((buf[16+w] >> 4) & 3) for w in range(8))
     print(f'{label:44s} {dt * 1e3:8.2f} ms/step  {S * NB * B / dt / 1e9:7.2f} Gframes/s{extra}', flush=True)
     d.close()
 
 
 full = WL.full_chain_blob(1)
 run('full chain', full)
+if os.environ.get('QUICK'): sys.exit(0)
 run('full chain, no output buffers', full, outputs=False)
 b = full.copy(); b['outputs']['delay_ms'] = 0.0
 run('no user delays (sub align only)', b)

@@ -46,10 +46,8 @@ def ops(kind):
             ('add', 't2', 's2', 't2'),         # ic2eq + a2*ic1eq
             ('mul', 't0', 'c2', 't0'),         # a3*v3
             ('add', v2, 't2', 't0'),           # v2
-            ('add', 't0', 't1', 't1'),         # 2*v1 (exact)
-            ('sub', 's1', 't0', 's1'),         # ic1eq = 2 v1 - ic1eq
-            ('add', 't0', v2, v2),             # 2*v2
-            ('sub', 's2', 't0', 's2')]         # ic2eq = 2 v2 - ic2eq
+            ('fma2', 's1', 't1', 's1'),        # ic1eq = 2 v1 - ic1eq: ONE fma(2, v1, -ic1eq).  2*v1 is exact, so the
+            ('fma2', 's2', v2, 's2')]          # ic2eq = 2 v2 - ic2eq  single rounding equals the reference's mul+sub bit for bit
     if kind == 'LP':
         return core
     if kind == 'HP':
@@ -68,6 +66,8 @@ def ops(kind):
 def scalar_line(op, d, a, b, i, tset=0):
     def r(n):
         return '%%[x%d]' % i if n == 'x' else '%%[%s]' % n
+    if op == 'fma2':
+        return "v_fma_f32 %s, 2.0, %s, -%s" % (r(d), r(a), r(b))
     return "v_%s_f32 %s, %s, %s" % (op, r(d), r(a), r(b))
 
 
@@ -78,8 +78,8 @@ def block_scalar(kind):
 # ---------------------------------------------------------------------------------------------------------
 # packed family: list scheduling over the whole 16-sample block
 # ---------------------------------------------------------------------------------------------------------
-NTSETS = 3          # rotating temp sets; sample i uses set i % NTSETS
-LAT_SLOTS = 3       # a dependent packed op wants >= 3 issue slots (12 cycles) after its producer
+NTSETS = int(os.environ.get('BL_NTSETS', 3))        # rotating temp sets; sample i uses set i % NTSETS
+LAT_SLOTS = int(os.environ.get('BL_LAT', 3))        # a dependent packed op wants >= this many issue slots after its producer
 
 
 def pk_operand(n, i):
@@ -98,6 +98,8 @@ def pk_line(op, d, a, b, i):
     an, asel = pk_operand(a, i)
     bn, bsel = pk_operand(b, i)
     assert not bsel, "coefficients are always the first source"
+    if op == 'fma2':
+        return "v_pk_fma_f32 %s, %%[two], %s, %s neg_lo:[0,0,1] neg_hi:[0,0,1]" % (dn, an, bn)
     mods = ''
     if asel == 'lo':
         mods += ' op_sel_hi:[0,1]'
@@ -189,9 +191,10 @@ def emit(name, kinds, out, packed):
     if packed:
         tn = ['t%d_%d' % (s, j) for s in range(NTSETS) for j in range(4)]
         ts = ', '.join('[%s] "=&v"(%s)' % (t, t) for t in tn)
-        cs = '[c01] "s"(c01), [c23] "s"(c23), [c45] "s"(c45)'
+        cs = '[c01] "s"(c01), [c23] "s"(c23), [c45] "s"(c45), [two] "s"(two)'
         out.append("__device__ __forceinline__ void %s(v2f (&x)[16], v2f &s1, v2f &s2, uint32_t kind, v2f c01, v2f c23, v2f c45) {" % name)
         out.append("    v2f %s;" % ', '.join(tn))
+        out.append("    const v2f two = {2.0f, 2.0f};")
     else:
         ts = ', '.join('[t%d] "=&v"(t%d)' % (i, i) for i in range(4))
         cs = ', '.join('[c%d] "s"(c%d)' % (i, i) for i in range(6))
@@ -214,7 +217,7 @@ HEADER = ["// %s — GENERATED by tools/gen_bandloops.py; do not edit by hand.",
 
 def main():
     allk = [('BQ', 1), ('LP', 2), ('HP', 3), ('PK', 4), ('SH', 5)]
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dspi_amd", "csrc")
+    here = os.environ.get('BL_OUT') or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dspi_amd", "csrc")
     for fname, packed, note in (("dspi_bandloops.inc", False, "// one stream per lane (v_mul_f32 / v_add_f32 / v_sub_f32), program order"),
                                 ("dspi_bandloops_pk.inc", True, "// two streams per lane (v_pk_mul_f32 / v_pk_add_f32), list-scheduled; needs v2f")):
         out = [HEADER[0] % fname] + HEADER[1:] + [note, ""]
