@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
     ap.add_argument("--blocks-per-step", type=int, default=25, help="packets per dspi_process call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--out-layout", choices=["tiled", "stream"], default="tiled",
+                    help="sample-word layout in HBM: the kernel's native tiles (DSPI_OUT_TILED) or stream-major S/PDIF pair buffers")
     args = ap.parse_args()
 
     import torch
@@ -151,13 +153,20 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     pcm = torch.randint(-16384, 16385, (S, frames, 2), dtype=torch.int16, device=dev, generator=g)
-    pairs = torch.empty((S, 4, frames, 2), dtype=torch.int32, device=dev)
-    sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
+    tiled = args.out_layout == "tiled"
+    R = ctx.tile_streams()
+    tiles = (S + R - 1) // R
+    if tiled:      # [tile][output][frame][R] / [tile][frame][R]  (include/dspi.h, DSPI_OUT_TILED)
+        pairs = torch.empty((tiles, 8, frames, R), dtype=torch.int32, device=dev)
+        sub = torch.empty((tiles, frames, R), dtype=torch.int32, device=dev)
+    else:          # [stream][pair][frame][2] / [stream][frame]
+        pairs = torch.empty((S, 4, frames, 2), dtype=torch.int32, device=dev)
+        sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
     peaks = torch.empty((S, NB, CHANNELS), dtype=torch.int16, device=dev)
     torch.cuda.synchronize()
 
     def step():
-        ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr())
+        ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled)
 
     for _ in range(args.warmup):
         step()
@@ -202,10 +211,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: full RP2350 chain (preamp+loudness+master PEQ+leveller/lookahead+crossfeed+2x9 matrix+9x10-band PEQ+gain+9 delay lines), "
                                    "96 kHz, 96-frame packets, int16 in, 4 S/PDIF pairs + PDM sub out",
+                       "out_layout": "tiled [tile][output][frame][128] (DSPI_OUT_TILED)" if tiled else "stream-major [stream][pair][frame][2]",
                        "streams_per_gpu": S, "blocks_per_step": NB, "frames_per_step_per_stream": frames,
                        "frames_per_s": frames_per_s, "realtime_streams": frames_per_s / FS, "parallelism": f"streams sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "chain_kernel<1,false>", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": "chain_kernel_pk<false,true,false>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": BYTES_PER_FRAME, "frames_per_launch": S * frames},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -286,6 +286,7 @@ int dspi_num_channels(const dspi_ctx *c) { return c ? c->sm.n_ch : DSPI_E_INVAL;
 int dspi_num_outputs(const dspi_ctx *c) { return c ? c->sm.n_out : DSPI_E_INVAL; }
 int dspi_num_pairs(const dspi_ctx *c) { return c ? c->sm.n_pairs : DSPI_E_INVAL; }
 uint32_t dspi_num_streams(const dspi_ctx *c) { return c ? c->n_streams : 0; }
+uint32_t dspi_tile_streams(const dspi_ctx *c) { return c ? (uint32_t)c->sm.row : 0; }
 void *dspi_hip_stream(dspi_ctx *c) { return c ? (void *)c->hs : nullptr; }
 
 int dspi_factory_defaults(dspi_ctx *c, int32_t stream) {
@@ -384,14 +385,17 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
 
     const size_t frames = (size_t)n_blocks * block_len;
     const size_t in_b = (size_t)c->n_streams * frames * (bit_depth == 24 ? 6 : 4);
-    const size_t pairs_b = (size_t)c->n_streams * c->sm.n_pairs * frames * 8;
-    const size_t sub_b = (size_t)c->n_streams * frames * 4;
+    const bool tiled = flags & DSPI_OUT_TILED;
+    const size_t padded = (size_t)c->n_wg * c->sm.row;          // tiled buffers cover whole tiles
+    const size_t pairs_b = tiled ? padded * (c->sm.n_out - 1) * frames * 4 : (size_t)c->n_streams * c->sm.n_pairs * frames * 8;
+    const size_t sub_b = (tiled ? padded : (size_t)c->n_streams) * frames * 4;
     const size_t peaks_b = (size_t)c->n_streams * n_blocks * c->sm.n_ch * 2;
     const bool dev = flags & DSPI_MEM_DEVICE;
 
     KArgs a{};
     a.state = c->d_state; a.dlines = c->d_dlines; a.ring = c->d_ring;
     a.n_streams = c->n_streams; a.n_blocks = n_blocks; a.block_len = block_len; a.bit_depth = (uint32_t)bit_depth;
+    a.tiled_out = tiled ? 1u : 0u;
     if (dev) {
         a.pcm = pcm_in; a.pairs = out->pairs; a.sub = out->sub; a.peaks = out->peaks;
     } else {

@@ -191,12 +191,12 @@ __device__ __forceinline__ void lds_barrier() {
 
 #ifdef DSPI_WAVE_TIMING
 // development aid: per-wave busy cycles (outside the barrier) and total cycles, summed over workgroups
-__device__ unsigned long long g_wave_timing[24];   // [2w] busy, [2w+1] total, [16+w] HW_ID of wave w of workgroup 0
+__device__ unsigned long long g_wave_timing[36];   // [2w] busy, [2w+1] total, [24+w] HW_ID of wave w of workgroup 0
 #define WT_DECL unsigned long long wt_busy = 0, wt_t0 = __builtin_amdgcn_s_memtime(), wt_start = wt_t0
 #define WT_BEFORE_BARRIER wt_busy += __builtin_amdgcn_s_memtime() - wt_t0
 #define WT_AFTER_BARRIER wt_t0 = __builtin_amdgcn_s_memtime()
 #define WT_FINISH(w) do { if (lane == 0) { atomicAdd(&g_wave_timing[(w) * 2], wt_busy); atomicAdd(&g_wave_timing[(w) * 2 + 1], __builtin_amdgcn_s_memtime() - wt_start); \
-    if (blockIdx.x == 0) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_wave_timing[16 + (w)] = hw; } } } while (0)
+    if (blockIdx.x == 0) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_wave_timing[24 + (w)] = hw; } } } while (0)
 #else
 #define WT_DECL
 #define WT_BEFORE_BARRIER
@@ -575,7 +575,12 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
             }
         }
         if (is_sub) {
-            if (a.sub && active) {
+            if (a.sub && active && a.tiled_out) {
+                int32_t *dst = a.sub + ((size_t)wg * F + frame0) * ROW + col;
+                const bool live = sub_active && enabled;
+#pragma unroll
+                for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[(size_t)i * ROW] = live ? f2i_sat(x[i] * 268435456.0f) : 0; }
+            } else if (a.sub && active) {
                 int32_t *dst = a.sub + (size_t)stream * F + frame0;
                 const bool live = sub_active && enabled;
                 if (!TAIL) {
@@ -601,7 +606,11 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
             }
             const int pair = o >> 1, side = o & 1;
             const bool partner_here = side ? (j >= 1) : (j + 1 < o_count && o + 1 < N - 1);
-            if (a.pairs && active) {
+            if (a.pairs && active && a.tiled_out) {
+                int32_t *dst = a.pairs + (((size_t)wg * (N - 1) + o) * F + frame0) * ROW + col;
+#pragma unroll
+                for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[(size_t)i * ROW] = wv[i]; }
+            } else if (a.pairs && active) {
                 int32_t *dst = a.pairs + (((size_t)stream * sm.n_pairs + pair) * F + frame0) * 2;
                 if (side == 1 && partner_here) {
                     if (!TAIL) {
@@ -979,7 +988,12 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
             if (a.peaks) a.peaks[((size_t)stream * g.n_blocks + kq) * sm.n_ch + 2 + o] = (uint16_t)p16;
         }
         if (is_sub) {
-            if (a.sub) {
+            if (a.sub && a.tiled_out) {
+                int32_t *dst = a.sub + ((size_t)wg * F + frame0) * ROW + col;
+                const bool live = sub_active && enabled;
+#pragma unroll
+                for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[(size_t)i * ROW] = live ? x[i] : 0; }
+            } else if (a.sub) {
                 int32_t *dst = a.sub + (size_t)stream * F + frame0;
                 const bool live = sub_active && enabled;
 #pragma unroll
@@ -995,7 +1009,11 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
             }
             const int pair = o >> 1, side = o & 1;
             const bool partner_here = side ? (j >= 1) : (j + 1 < o_count && o + 1 < N - 1);
-            if (a.pairs) {
+            if (a.pairs && a.tiled_out) {
+                int32_t *dst = a.pairs + (((size_t)wg * (N - 1) + o) * F + frame0) * ROW + col;
+#pragma unroll
+                for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[(size_t)i * ROW] = wv[i]; }
+            } else if (a.pairs) {
                 int32_t *dst = a.pairs + (((size_t)stream * sm.n_pairs + pair) * F + frame0) * 2;
                 if (side == 1 && partner_here) {
 #pragma unroll
@@ -1248,7 +1266,7 @@ __global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
 // ------------------------------------------------------------------------------------------
 size_t chain_lds_bytes(int flavor, int packed) {
     const StateMap sm = make_state_map(flavor);
-    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t);
+    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox : 0)) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);
 }
 
 template <int FLAVOR>
@@ -1319,10 +1337,10 @@ hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStre
 }
 
 #ifdef DSPI_WAVE_TIMING
-extern "C" int dspi_debug_wave_timing(unsigned long long *out24, int reset) {
-    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_wave_timing), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+extern "C" int dspi_debug_wave_timing(unsigned long long *out36, int reset) {
+    if (hipMemcpyFromSymbol(out36, HIP_SYMBOL(g_wave_timing), sizeof(unsigned long long) * 36) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[24] = {0};
+        unsigned long long z[36] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_timing), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

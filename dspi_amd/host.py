@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("DSPI_LIB") or (Path(__file__).resolve().parent /
 
 ALL = -1
 MEM_DEVICE = 0x1
+OUT_TILED = 0x2
 E_NODEVICE = -11
 E_UNSUPPORTED = -14
 
@@ -49,6 +50,8 @@ def lib() -> C.CDLL:
         getattr(L, name).argtypes = [vp]
     L.dspi_num_streams.argtypes = [vp]
     L.dspi_num_streams.restype = u32
+    L.dspi_tile_streams.argtypes = [vp]
+    L.dspi_tile_streams.restype = u32
     L.dspi_factory_defaults.argtypes = [vp, i32]
     L.dspi_load_bulk.argtypes = [vp, i32, vp, C.c_size_t]
     L.dspi_collect_bulk.argtypes = [vp, i32, vp, C.c_size_t]
@@ -153,25 +156,47 @@ class Dspi:
         return buf.raw[:n]
 
     # ---- audio ----
+    def tile_streams(self) -> int:
+        """R of the tiled layouts (dspi.h DSPI_OUT_TILED): 128 float / 64 Q28."""
+        return int(self.L.dspi_tile_streams(self.h))
+
     def process_host(self, pcm: np.ndarray, n_blocks: int, block_len: int, bit_depth: int = 16,
-                     want_pairs=True, want_sub=True, want_peaks=True):
+                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False):
         """Host-memory convenience path (tests): pcm = int16 [streams][frames][2] or uint8 [streams][frames*6].
-        Returns (pairs [S][P][F][2], sub [S][F], peaks [S][blocks][C])."""
+        Returns (pairs [S][P][F][2], sub [S][F], peaks [S][blocks][C]); with tiled=True the sample words come back in
+        the DSPI_OUT_TILED layout: pairs [tiles][outputs][F][R], sub [tiles][F][R] (see untile())."""
         S, F = self.n_streams, n_blocks * block_len
         pcm = np.ascontiguousarray(pcm)
         assert pcm.nbytes == S * F * (6 if bit_depth == 24 else 4), (pcm.shape, S, F)
-        pairs = np.zeros((S, self.P, F, 2), dtype=np.int32) if want_pairs else None
-        sub = np.zeros((S, F), dtype=np.int32) if want_sub else None
+        if tiled:
+            R = self.tile_streams(); nt = (S + R - 1) // R
+            pairs = np.zeros((nt, self.P * 2, F, R), dtype=np.int32) if want_pairs else None
+            sub = np.zeros((nt, F, R), dtype=np.int32) if want_sub else None
+        else:
+            pairs = np.zeros((S, self.P, F, 2), dtype=np.int32) if want_pairs else None
+            sub = np.zeros((S, F), dtype=np.int32) if want_sub else None
         peaks = np.zeros((S, n_blocks, self.C), dtype=np.uint16) if want_peaks else None
         out = _Out(pairs.ctypes.data if want_pairs else None, sub.ctypes.data if want_sub else None, peaks.ctypes.data if want_peaks else None)
-        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), 0), "process")
+        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), OUT_TILED if tiled else 0), "process")
         return pairs, sub, peaks
 
+    def untile(self, pairs_t: np.ndarray, sub_t: np.ndarray):
+        """Tiled -> stream-major view of process_host(tiled=True) results (test helper)."""
+        S = self.n_streams
+        pairs = sub = None
+        if pairs_t is not None:
+            nt, O, F, R = pairs_t.shape
+            pairs = pairs_t.transpose(0, 3, 1, 2).reshape(nt * R, O // 2, 2, F).transpose(0, 1, 3, 2)[:S].copy()
+        if sub_t is not None:
+            nt, F, R = sub_t.shape
+            sub = sub_t.transpose(0, 2, 1).reshape(nt * R, F)[:S].copy()
+        return pairs, sub
+
     def process_device(self, pcm_ptr: int, n_blocks: int, block_len: int, bit_depth: int = 16,
-                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0):
+                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0, tiled: bool = False):
         """Zero-copy path: raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous, see sync()."""
         out = _Out(pairs_ptr or None, sub_ptr or None, peaks_ptr or None)
-        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE), "process")
+        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE | (OUT_TILED if tiled else 0)), "process")
 
     def sync(self):
         self._ck(self.L.dspi_sync(self.h), "sync")

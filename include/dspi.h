@@ -63,6 +63,7 @@ extern "C" {
 
 /* dspi_process flags */
 #define DSPI_MEM_DEVICE 0x1u       /* pcm_in and every pointer in dspi_out are device pointers (zero-copy) */
+#define DSPI_OUT_TILED 0x2u        /* pairs / sub use the device-native tiled layout described at dspi_out */
 
 typedef struct dspi_ctx dspi_ctx;
 
@@ -70,7 +71,16 @@ typedef struct dspi_ctx dspi_ctx;
  *   pairs      int32 [stream][pair][F][2]   pair p = outputs 2p,2p+1; 24-bit sample per word
  *   sub        int32 [stream][F]            PDM sub channel, Q28 (zeros when the firmware would push nothing)
  *   peaks      uint16 [stream][block][C]    per-packet peak meters (global_status.peaks, config.h:455-460)
- * where C = 11 / 7 channels and pair count = 4 / 2. */
+ * where C = 11 / 7 channels and pair count = 4 / 2.
+ *
+ * With DSPI_OUT_TILED the sample words are stream-minor instead ("tiles" of R = dspi_tile_streams() consecutive
+ * streams, 128 float / 64 Q28; tile = stream / R, column = stream % R):
+ *   pairs      int32 [tile][output][F][R]   output o = 0 .. 2*pairs-1 (pair o/2, side o%2), same 24-bit words
+ *   sub        int32 [tile][F][R]
+ * Buffers cover whole tiles (ceil(n_streams / R) of them); columns past n_streams are never written.
+ * This is how the kernel produces the samples (one 512-byte row per frame per output, like its delay lines): the
+ * layout for a GPU-resident consumer.  The stream-major layout above is the per-device view (one S/PDIF pair buffer
+ * per stream) and costs scattered 4-byte writes. */
 typedef struct dspi_out {
     int32_t *pairs;
     int32_t *sub;
@@ -86,6 +96,7 @@ int dspi_num_channels(const dspi_ctx *ctx);   /* 11 / 7 */
 int dspi_num_outputs(const dspi_ctx *ctx);    /* 9 / 5  */
 int dspi_num_pairs(const dspi_ctx *ctx);      /* 4 / 2  */
 uint32_t dspi_num_streams(const dspi_ctx *ctx);
+uint32_t dspi_tile_streams(const dspi_ctx *ctx);   /* R of the tiled layouts: 128 / 64 */
 
 /* ---- whole-state blobs ---------------------------------------------------------------- */
 /* REQ_FACTORY_RESET / loading an empty preset slot: flash_storage.c:1144-1238, :811-833 */

@@ -135,6 +135,29 @@ def test_per_stream_presets_and_clip_flags():
     d.close()
 
 
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+def test_tiled_output_layout(flavor):
+    """DSPI_OUT_TILED ([tile][output][frame][R]) carries exactly the words of the stream-major layout: packed and
+    one-stream kernels (two streams get their own preset), ragged last tile, tail packets on the second call."""
+    fs, S = 48000, (200 if flavor else 100)
+    blob = WL.full_chain_blob(flavor)
+    ctx = []
+    for _ in range(2):
+        d = Dspi(flavor, S, device=0)
+        d.set_rate(fs); d.set_volume(-12 * 256); assert d.load_bulk(blob) == 0
+        for s_, db in ((5, -9.0), (130 % S, 3.0)):
+            d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", db), stream=s_)
+        ctx.append(d)
+    assert ctx[0].tile_streams() == (128 if flavor else 64)
+    for B, blocks in ((48, 10), (45, 7)):
+        pcm = WL.synth_pcm16(S, B * blocks, fs)
+        p0, s0, k0 = ctx[0].process_host(pcm, blocks, B)
+        pt, st, k1 = ctx[1].process_host(pcm, blocks, B, tiled=True)
+        p1, s1 = ctx[1].untile(pt, st)
+        assert np.array_equal(p0, p1) and np.array_equal(s0, s1) and np.array_equal(k0, k1), (B, blocks)
+    for d in ctx: d.close()
+
+
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_fixtures_on_gpu(path):
     """Vectors generated from the reference's own leaf sources (tests/golden/make_golden.py).  Skipped: the glibc-libm vector

@@ -28,11 +28,11 @@ def run(label, blob, outputs=True, steps=4):
     extra = ''
     if os.environ.get('DSPI_LIB', '').endswith('timing.so'):
         import ctypes
-        buf = (ctypes.c_ulonglong * 24)()
+        buf = (ctypes.c_ulonglong * 36)()
         d.L.dspi_debug_wave_timing(buf, 1)
         nwg = (S + 127) // 128
-        per = [buf[i] / nwg / (steps + 1) for i in range(16)]     # cycles per workgroup per launch
-        extra = '\n      busy/total Mcyc per WG: ' + ' '.join(f'w{w}:{per[2*w]/1e6:.2f}/{per[2*w+1]/1e6:.2f}' for w in range(8)) + '  simd(wg0): ' + ' '.join(str((buf[16+w] >> 4) & 3) for w in range(8))
+        per = [buf[i] / nwg / (steps + 1) for i in range(24)]     # cycles per workgroup per launch
+        extra = '\n      busy/total Mcyc per WG: ' + ' '.join(f'w{w}:{per[2*w]/1e6:.2f}/{per[2*w+1]/1e6:.2f}' for w in range(12)) + '  simd(wg0): ' + ' '.join(str((buf[24+w] >> 4) & 3) for w in range(12))
     print(f'{label:44s} {dt * 1e3:8.2f} ms/step  {S * NB * B / dt / 1e9:7.2f} Gframes/s{extra}', flush=True)
     d.close()
 
