@@ -1284,31 +1284,30 @@ static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_
     return hipGetLastError();
 }
 
-template <bool TAIL, bool LEV, bool PCM24>
+template <bool TAIL, bool LEV, bool PCM24, bool TILED>
 static hipError_t launch_chain_pk_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(1, 1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
+    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24, TILED>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
     return hipGetLastError();
 }
 
+template <bool TAIL, bool LEV>
+static hipError_t launch_chain_pk_2(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    const bool p24 = args.bit_depth == 24, tl = args.tiled_out != 0;
+    if (p24) return tl ? launch_chain_pk_t<TAIL, LEV, true, true>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, true, false>(args, n_items, stream);
+    return tl ? launch_chain_pk_t<TAIL, LEV, false, true>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, false, false>(args, n_items, stream);
+}
+
 static hipError_t launch_chain_pk(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream) {
-    const int v = ((args.block_len % T) ? 4 : 0) | (leveller_on ? 2 : 0) | (args.bit_depth == 24 ? 1 : 0);
-    switch (v) {
-        case 0: return launch_chain_pk_t<false, false, false>(args, n_items, stream);
-        case 1: return launch_chain_pk_t<false, false, true>(args, n_items, stream);
-        case 2: return launch_chain_pk_t<false, true, false>(args, n_items, stream);
-        case 3: return launch_chain_pk_t<false, true, true>(args, n_items, stream);
-        case 4: return launch_chain_pk_t<true, false, false>(args, n_items, stream);
-        case 5: return launch_chain_pk_t<true, false, true>(args, n_items, stream);
-        case 6: return launch_chain_pk_t<true, true, false>(args, n_items, stream);
-        default: return launch_chain_pk_t<true, true, true>(args, n_items, stream);
-    }
+    const bool tail = (args.block_len % T) != 0;
+    if (tail) return leveller_on ? launch_chain_pk_2<true, true>(args, n_items, stream) : launch_chain_pk_2<true, false>(args, n_items, stream);
+    return leveller_on ? launch_chain_pk_2<false, true>(args, n_items, stream) : launch_chain_pk_2<false, false>(args, n_items, stream);
 }
 
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream) {

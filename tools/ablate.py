@@ -9,8 +9,9 @@ from dspi_amd.host import Dspi
 S = int(os.environ.get('S', 65536)); NB = 25; B = 96; FS = 96000
 dev = torch.device('cuda', 0)
 pcm = torch.randint(-16384, 16385, (S, NB * B, 2), dtype=torch.int16, device=dev)
-pairs = torch.empty((S, 4, NB * B, 2), dtype=torch.int32, device=dev)
-sub = torch.empty((S, NB * B), dtype=torch.int32, device=dev)
+TILED = not os.environ.get('STREAM_MAJOR')
+pairs = torch.empty((S * 8 * NB * B,), dtype=torch.int32, device=dev)      # either layout: same size (S % 128 == 0)
+sub = torch.empty((S * NB * B,), dtype=torch.int32, device=dev)
 peaks = torch.empty((S, NB, 11), dtype=torch.int16, device=dev)
 
 
@@ -19,10 +20,10 @@ def run(label, blob, outputs=True, steps=4):
     d.set_rate(FS); d.set_volume(-20 * 256)
     assert d.load_bulk(blob) == 0
     args = (pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr()) if outputs else (0, 0, 0)
-    d.process_device(pcm.data_ptr(), NB, B, 16, *args); d.sync()
+    d.process_device(pcm.data_ptr(), NB, B, 16, *args, tiled=TILED); d.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        d.process_device(pcm.data_ptr(), NB, B, 16, *args)
+        d.process_device(pcm.data_ptr(), NB, B, 16, *args, tiled=TILED)
     d.sync()
     dt = (time.perf_counter() - t0) / steps
     extra = ''
@@ -32,7 +33,7 @@ def run(label, blob, outputs=True, steps=4):
         d.L.dspi_debug_wave_timing(buf, 1)
         nwg = (S + 127) // 128
         per = [buf[i] / nwg / (steps + 1) for i in range(24)]     # cycles per workgroup per launch
-        extra = '\n      busy/total Mcyc per WG: ' + ' '.join(f'w{w}:{per[2*w]/1e6:.2f}/{per[2*w+1]/1e6:.2f}' for w in range(12)) + '  simd(wg0): ' + ' '.join(str((buf[24+w] >> 4) & 3) for w in range(12))
+        extra = '\n      busy/total Mcyc per WG: ' + ' '.join(f'w{w}:{per[2*w]/1e6:.2f}/{per[2*w+1]/1e6:.2f}' for w in range(12)) + '  (r0 intake r1 hand-off r2 idle r3.. outputs 0 3 6 | 1 4 7 | 2 5 8)  simd(wg0): ' + ' '.join(str((buf[24+w] >> 4) & 3) for w in range(12))
     print(f'{label:44s} {dt * 1e3:8.2f} ms/step  {S * NB * B / dt / 1e9:7.2f} Gframes/s{extra}', flush=True)
     d.close()
 
