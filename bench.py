@@ -196,13 +196,17 @@ def main():
     frames_per_s = total_frames / elapsed
     if rank == 0:
         achieved_gbs = S * frames * BYTES_PER_FRAME / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/prof.sh + tools/prof_summary.py);
+        # counters cannot be collected inside the timed run, so this is the committed figure of the latest profile
+        traffic, traffic_src = None, None
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                t = json.load(open(tpath))
+                if t.get("out_layout", "stream") == args.out_layout and t.get("hbm_bytes_per_launch"):
+                    traffic, traffic_src = t["hbm_bytes_per_launch"], os.path.basename(tpath)
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "audio samples/s (whole node), 96 kHz 11-ch 10-band PEQ; % HBM roofline",
             "value": frames_per_s * CHANNELS, "unit": "samples/s",
@@ -215,7 +219,7 @@ def main():
                        "streams_per_gpu": S, "blocks_per_step": NB, "frames_per_step_per_stream": frames,
                        "frames_per_s": frames_per_s, "realtime_streams": frames_per_s / FS, "parallelism": f"streams sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "chain_kernel_pk<false,true,false>", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "chain_kernel_pk<false,true,false>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_frame": BYTES_PER_FRAME, "frames_per_launch": S * frames},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -64,6 +64,7 @@ if counters:
         if kernel_avg_us:
             lines.append(f"- at {kernel_avg_us:.0f} us/launch: {tot / kernel_avg_us / 1e6:.3f} TB/s moved, {104 * frames / kernel_avg_us / 1e6:.3f} TB/s algorithmic")
         hb["hbm_bytes_per_launch"] = tot
+        hb["out_layout"] = os.environ.get("OUT_LAYOUT", "tiled")
         json.dump(hb, open(os.path.join(os.path.dirname(dst), "traffic_" + os.path.basename(dst).split("_")[0] + ".json"), "w"))
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 open(dst, "w").write("\n".join(lines) + "\n")
