@@ -191,13 +191,17 @@ __device__ __forceinline__ void lds_barrier() {
 
 #ifdef DSPI_WAVE_TIMING
 // development aid: per-wave busy cycles (outside the barrier) and total cycles, summed over workgroups
-__device__ unsigned long long g_wave_timing[36];   // [2w] busy, [2w+1] total, [24+w] HW_ID of wave w of workgroup 0
+__device__ unsigned long long g_wave_timing[36 + 48];   // [36 + 4*rank + k]: phase timers of the packed output waves   // [2w] busy, [2w+1] total, [24+w] HW_ID of wave w of workgroup 0
+#define WT_PHASE(r, k, t) do { if (lane == 0) atomicAdd(&g_wave_timing[36 + 4 * (r) + (k)], (unsigned long long)(t)); } while (0)
+#define WT_NOW() __builtin_amdgcn_s_memtime()
 #define WT_DECL unsigned long long wt_busy = 0, wt_t0 = __builtin_amdgcn_s_memtime(), wt_start = wt_t0
 #define WT_BEFORE_BARRIER wt_busy += __builtin_amdgcn_s_memtime() - wt_t0
 #define WT_AFTER_BARRIER wt_t0 = __builtin_amdgcn_s_memtime()
 #define WT_FINISH(w) do { if (lane == 0) { atomicAdd(&g_wave_timing[(w) * 2], wt_busy); atomicAdd(&g_wave_timing[(w) * 2 + 1], __builtin_amdgcn_s_memtime() - wt_start); \
     if (blockIdx.x == 0) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_wave_timing[24 + (w)] = hw; } } } while (0)
 #else
+#define WT_PHASE(r, k, t)
+#define WT_NOW() 0ull
 #define WT_DECL
 #define WT_BEFORE_BARRIER
 #define WT_AFTER_BARRIER
@@ -1336,10 +1340,10 @@ hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStre
 }
 
 #ifdef DSPI_WAVE_TIMING
-extern "C" int dspi_debug_wave_timing(unsigned long long *out36, int reset) {
-    if (hipMemcpyFromSymbol(out36, HIP_SYMBOL(g_wave_timing), sizeof(unsigned long long) * 36) != hipSuccess) return -1;
+extern "C" int dspi_debug_wave_timing(unsigned long long *out84, int reset) {
+    if (hipMemcpyFromSymbol(out84, HIP_SYMBOL(g_wave_timing), sizeof(unsigned long long) * 84) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[36] = {0};
+        unsigned long long z[84] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_timing), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

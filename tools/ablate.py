@@ -29,11 +29,13 @@ def run(label, blob, outputs=True, steps=4):
     extra = ''
     if os.environ.get('DSPI_LIB', '').endswith('timing.so'):
         import ctypes
-        buf = (ctypes.c_ulonglong * 36)()
+        buf = (ctypes.c_ulonglong * 84)()
         d.L.dspi_debug_wave_timing(buf, 1)
         nwg = (S + 127) // 128
         per = [buf[i] / nwg / (steps + 1) for i in range(24)]     # cycles per workgroup per launch
         extra = '\n      busy/total Mcyc per WG: ' + ' '.join(f'w{w}:{per[2*w]/1e6:.2f}/{per[2*w+1]/1e6:.2f}' for w in range(12)) + '  (r0 intake r1 hand-off r2 idle r3.. outputs 0 3 6 | 1 4 7 | 2 5 8)  simd(wg0): ' + ' '.join(str((buf[24+w] >> 4) & 3) for w in range(12))
+    if os.environ.get('DSPI_LIB', '').endswith('timing.so'):
+        extra += '\n      output phases Mcyc (eq / wait dl / emit / dl store): ' + ' '.join('o%d:' % o + '/'.join(f'{buf[36 + 4 * (3 + o) + k] / nwg / (steps + 1) / 1e6:.2f}' for k in range(4)) for o in range(9))
     print(f'{label:44s} {dt * 1e3:8.2f} ms/step  {S * NB * B / dt / 1e9:7.2f} Gframes/s{extra}', flush=True)
     d.close()
 
