@@ -198,13 +198,14 @@ def main():
         achieved_gbs = S * frames * BYTES_PER_FRAME / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/prof.sh + tools/prof_summary.py);
         # counters cannot be collected inside the timed run, so this is the committed figure of the latest profile
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_insts = None, None, None
         import glob
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
             try:
                 t = json.load(open(tpath))
                 if t.get("out_layout", "stream") == args.out_layout and t.get("hbm_bytes_per_launch"):
                     traffic, traffic_src = t["hbm_bytes_per_launch"], os.path.basename(tpath)
+                    valu_insts = t.get("valu_insts_per_launch")
             except Exception:
                 pass
         out = {
@@ -219,8 +220,13 @@ def main():
                        "streams_per_gpu": S, "blocks_per_step": NB, "frames_per_step_per_stream": frames,
                        "frames_per_s": frames_per_s, "realtime_streams": frames_per_s / FS, "parallelism": f"streams sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "chain_kernel_pk<false,true,false>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_frame": BYTES_PER_FRAME, "frames_per_launch": S * frames},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "chain_kernel_pk<false, true, false, %s>" % ("true" if tiled else "false"), "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_frame": BYTES_PER_FRAME, "frames_per_launch": S * frames,
+                         # SURVEY.md §8d asks for both sides of the ridge.  VALU: wave-instructions per launch (SQ_INSTS_VALU of the
+                         # committed profile, same workload) / kernel time / (1024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction)
+                         "valu_fraction": (valu_insts / (kernel_ms * 1e-3) / (1024 * 2.4e9 / 4.0)) if valu_insts else None,
+                         "hbm_fraction_measured_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "binds": "valu"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -19,7 +19,7 @@ if os.path.exists(tr):
         lines.append(f"| `{short}` | {calls} | {total:.1f} | {avg:.1f} | {pct:.2f} |")
         if "chain_kernel" in name:
             kernel_avg_us = avg
-    q = "select kernel_name, vgpr_count, sgpr_count, lds_block_size, scratch_size, workgroup_size, grid_size from kernels where kernel_name like '%chain_kernel%' limit 1"
+    q = "select name, vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x from kernels where name like '%chain_kernel%' limit 1"
     try:
         for r in db.execute(q):
             lines += ["", f"chain kernel resources: VGPR {r[1]}, SGPR {r[2]}, LDS {r[3]} B/workgroup, scratch {r[4]} B/lane, workgroup {r[5]}, grid {r[6]}"]
@@ -43,10 +43,10 @@ if counters:
     d = {k: v[0] for k, v in counters.items()}
     lines += ["", "## Derived", ""]
     if "SQ_INSTS_VALU" in d:
-        lines.append(f"- VALU wave-instructions per frame (x64 streams per wave): {d['SQ_INSTS_VALU'] * 64 / frames:.1f}")
+        lines.append(f"- VALU wave-instructions per stream-frame (x64 lanes; the packed kernel carries two streams per lane): {d['SQ_INSTS_VALU'] * 64 / frames:.1f}")
     if "SQ_INSTS_VALU" in d and "GRBM_GUI_ACTIVE" in d:
         cyc = d["GRBM_GUI_ACTIVE"] / 8.0
-        lines.append(f"- kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs): {cyc:.4g}; VALU issue utilisation = INSTS_VALU*2 cycles / (1024 SIMDs x cycles) = {d['SQ_INSTS_VALU'] * 2 / (1024 * cyc):.3f}")
+        lines.append(f"- kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs): {cyc:.4g}; VALU issue utilisation = INSTS_VALU x 4.1 cycles (tools/probe/probe3: one wave-instruction per ~4.1 cycles per SIMD) / (1024 SIMDs x cycles) = {d['SQ_INSTS_VALU'] * 4.1 / (1024 * cyc):.3f}")
     if "SQ_WAVE_CYCLES" in d:
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if k in d:
@@ -65,6 +65,7 @@ if counters:
             lines.append(f"- at {kernel_avg_us:.0f} us/launch: {tot / kernel_avg_us / 1e6:.3f} TB/s moved, {104 * frames / kernel_avg_us / 1e6:.3f} TB/s algorithmic")
         hb["hbm_bytes_per_launch"] = tot
         hb["out_layout"] = os.environ.get("OUT_LAYOUT", "tiled")
+        if "SQ_INSTS_VALU" in d: hb["valu_insts_per_launch"] = d["SQ_INSTS_VALU"]
         json.dump(hb, open(os.path.join(os.path.dirname(dst), "traffic_" + os.path.basename(dst).split("_")[0] + ".json"), "w"))
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 open(dst, "w").write("\n".join(lines) + "\n")
