@@ -1,24 +1,25 @@
-// dspi_kernels.hip — the DSPi per-sample chain as one fused, persistent gfx950 kernel.
+// dspi_kernels.hip — the DSPi per-sample chain as fused, persistent gfx950 kernels.
 //
 // Reference path: process_audio_packet, firmware/DSPi/usb_audio.c:560-967 (RP2350 float) and
 // :968-1283 (RP2040 Q28), with its leaf loops in dsp_pipeline.c:281-365, dsp_process_rp2040.S:225-394,
 // leveller.c:148-389, crossfeed.c:132-180.
 //
-// Mapping:
-//   * one lane  = one stream; one 256-thread workgroup = 64 streams x 4 waves
-//   * wave 0    = "master": input convert + preamp, loudness, master L/R EQ, leveller, master
-//                 peaks, crossfeed -> post-crossfeed L/R chunk into LDS
-//     waves 1-3 = "outputs": matrix mix, per-output EQ, gain, delay line, peaks, int24 / Q28 words
-//   * the time loop runs inside the kernel (T-frame chunks, packet semantics kept per block);
-//     filter state stays in LDS for the whole launch, coefficients come from one DevImage through
-//     scalar loads (all lanes of a launch share the image), delay lines / leveller ring are
-//     [position][lane] in HBM so every access is a 256-byte coalesced row
-//   * no MFMA: every stage is a per-stream recurrence.  No contraction, FTZ on (build flags).
+// Two kernels share the data layout:
+//   * chain_kernel_pk (dspi_chain_pk.inc, included below): float flavour, TWO streams per lane on packed FP32,
+//     128 streams x 12 waves per workgroup — the bench path.
+//   * chain_kernel (this file): ONE stream per lane, 64 streams x 4 waves — the Q28 flavour (integer arithmetic
+//     has no packed form) and float lanes whose two streams carry different parameter images.
+//       wave 0    = "master": input convert + preamp, loudness, master L/R EQ, leveller, master peaks,
+//                   crossfeed -> post-crossfeed L/R chunk into LDS
+//       waves 1-3 = "outputs": matrix mix, per-output EQ, gain, delay line, peaks, int24 / Q28 words
+// Common to both: the time loop runs inside the kernel (16-frame chunks, packet semantics kept per block); filter
+// state stays in LDS for the whole launch, coefficients come from one DevImage through scalar loads (all lanes of a
+// launch share the image), delay lines / leveller ring are [position][stream] rows in HBM so every access is one
+// coalesced row.  No MFMA: every stage is a per-stream recurrence.  No contraction, FTZ on (build flags).
 //
-// The leveller is a two-pass-per-packet algorithm (envelope over the whole packet, then a gain
-// ramp over the same packet).  Pass 1 of packet k and pass 2 of packet k-1 are interleaved
-// chunk by chunk through a [2][1024][lane] ring in HBM that doubles as the 480-sample lookahead
-// line, so the master wave never holds more than one chunk in registers.
+// The leveller is a two-pass-per-packet algorithm (envelope over the whole packet, then a gain ramp over the same
+// packet).  Pass 1 of packet k and pass 2 of packet k-1 are interleaved chunk by chunk through a [2][1024][stream]
+// ring in HBM that doubles as the 480-sample lookahead line, so no wave ever holds more than one chunk in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
