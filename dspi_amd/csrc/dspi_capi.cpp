@@ -35,6 +35,12 @@ struct dspi_ctx {
     // 1 = lanes whose two streams both belong (float: packed kernel), 2/3 = lanes where only stream 0 / 1 belongs
     std::vector<std::vector<WgItem>> image_items[4];
     std::vector<uint32_t> image_item_offset[4];
+    // chain launches: the same work lists concatenated over images, grouped by what the kernels are specialised on
+    // (float: leveller on/off), so a dspi_process is a handful of launches however many presets are in play
+    std::vector<WgItem> launch_items[2][4];
+    uint32_t launch_item_offset[2][4] = {};
+    WgItem *d_litems = nullptr; size_t d_litems_cap = 0;
+    bool launch_dirty = true;
     // device
     hipStream_t hs = nullptr;
     uint32_t *d_state = nullptr, *d_dlines = nullptr, *d_ring = nullptr;
@@ -147,6 +153,34 @@ int rebuild_assignment(dspi_ctx *c) {
                                         hipMemcpyHostToDevice, c->hs));
     HIPCK(c, hipStreamSynchronize(c->hs));
     c->assignment_dirty = false;
+    c->launch_dirty = true;
+    return 0;
+}
+
+int rebuild_launch_lists(dspi_ctx *c) {
+    size_t total = 0;
+    for (int lev = 0; lev < 2; lev++)
+        for (int k = 0; k < 4; k++) {
+            auto &v = c->launch_items[lev][k];
+            v.clear();
+            for (size_t i = 0; i < c->images.size(); i++) {
+                if (c->image_refs[i] == 0) continue;
+                const int ilev = (c->flavor && (c->image_flags[i] & IF_LEVELLER_ON)) ? 1 : 0;
+                if (ilev != lev) continue;
+                for (WgItem it : c->image_items[k][i]) { it.image = (uint32_t)i; v.push_back(it); }
+            }
+            c->launch_item_offset[lev][k] = (uint32_t)total;
+            total += v.size();
+        }
+    int rc = ensure(c, c->d_litems, c->d_litems_cap, total * sizeof(WgItem));
+    if (rc) return rc;
+    HIPCK(c, hipStreamSynchronize(c->hs));      // no launch may still be reading the list we overwrite
+    for (int lev = 0; lev < 2; lev++)
+        for (int k = 0; k < 4; k++)
+            if (!c->launch_items[lev][k].empty())
+                HIPCK(c, hipMemcpy(c->d_litems + c->launch_item_offset[lev][k], c->launch_items[lev][k].data(),
+                                   c->launch_items[lev][k].size() * sizeof(WgItem), hipMemcpyHostToDevice));
+    c->launch_dirty = false;
     return 0;
 }
 
@@ -178,6 +212,7 @@ int commit_params(dspi_ctx *c) {
             DevImage img;
             p.build_image(img);
             if (c->image_flags.size() <= i) c->image_flags.resize(i + 1, 0u);
+            if ((c->image_flags[i] ^ img.flags) & IF_LEVELLER_ON) c->launch_dirty = true;
             c->image_flags[i] = img.flags;
             HIPCK(c, hipMemcpy(c->d_images + i, &img, sizeof(img), hipMemcpyHostToDevice));   // synchronous: `img` is a local
             p.dirty = false;
@@ -190,6 +225,7 @@ int commit_params(dspi_ctx *c) {
             p.ops = StateOps{};
         }
     }
+    if (c->launch_dirty) { int rc = rebuild_launch_lists(c); if (rc) return rc; }
     return 0;
 }
 
@@ -273,7 +309,7 @@ void dspi_destroy(dspi_ctx *c) {
     if (c->device != DSPI_DEVICE_NONE) {
         (void)hipSetDevice(c->device);
         if (c->hs) (void)hipStreamSynchronize(c->hs);
-        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, c->d_in,
+        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, c->d_in,
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
             if (p) (void)hipFree(p);
         if (c->hs) (void)hipStreamDestroy(c->hs);
@@ -406,26 +442,25 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         if (out->sub) { if ((rc = ensure(c, c->d_sub, c->d_sub_cap, sub_b))) return rc; a.sub = c->d_sub; }
         if (out->peaks) { if ((rc = ensure(c, c->d_peaks, c->d_peaks_cap, peaks_b))) return rc; a.peaks = c->d_peaks; }
     }
-    for (size_t i = 0; i < c->images.size(); i++) {
-        if (c->image_refs[i] == 0) continue;
-        a.img = c->d_images + i;
-        // float flavour: lanes with both streams in this image go to the packed kernel (list 1), lanes with one stream
-        // to the scalar kernel per component (lists 2, 3).  Q28: one scalar launch over list 0.
-        struct Launch { int list; int packed; uint32_t comp; };
-        static const Launch kF32[] = {{1, 1, 0}, {2, 0, 0}, {3, 0, 1}};
-        static const Launch kQ28[] = {{0, 0, 0}};
-        const Launch *ls = c->flavor ? kF32 : kQ28;
-        const int nl = c->flavor ? 3 : 1;
+    a.img = c->d_images;
+    // float flavour: lanes with both streams on one image go to the packed kernel (list 1), lanes with one stream of an
+    // image to the one-stream kernel per component (lists 2, 3); Q28: the one-stream kernel over list 0.  One launch
+    // per (leveller on/off, list) covers every image.
+    struct Launch { int list; int packed; uint32_t comp; };
+    static const Launch kF32[] = {{1, 1, 0}, {2, 0, 0}, {3, 0, 1}};
+    static const Launch kQ28[] = {{0, 0, 0}};
+    const Launch *ls = c->flavor ? kF32 : kQ28;
+    const int nl = c->flavor ? 3 : 1;
+    for (int lev = 0; lev < 2; lev++)
         for (int l = 0; l < nl; l++) {
-            const auto &items = c->image_items[ls[l].list][i];
+            const auto &items = c->launch_items[lev][ls[l].list];
             if (items.empty()) continue;
-            a.items = c->d_items + c->image_item_offset[ls[l].list][i];
+            a.items = c->d_litems + c->launch_item_offset[lev][ls[l].list];
             a.comp = ls[l].comp;
-            hipError_t e = launch_chain(c->flavor, ls[l].packed, (c->image_flags[i] & IF_LEVELLER_ON) != 0, a, (uint32_t)items.size(), c->hs);
+            hipError_t e = launch_chain(c->flavor, ls[l].packed, lev != 0, a, (uint32_t)items.size(), c->hs);
             if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
             if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));
         }
-    }
     if (!dev) {
         if (out->pairs) HIPCK(c, hipMemcpyAsync(out->pairs, c->d_pairs, pairs_b, hipMemcpyDeviceToHost, c->hs));
         if (out->sub) HIPCK(c, hipMemcpyAsync(out->sub, c->d_sub, sub_b, hipMemcpyDeviceToHost, c->hs));

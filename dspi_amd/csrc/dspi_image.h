@@ -126,7 +126,7 @@ struct StateOps {
 
 struct WgItem {
     uint32_t wg;
-    uint32_t pad;
+    uint32_t image;  // chain launches: index of the workgroup's parameter image (one launch covers every image)
     uint64_t mask;   // lanes of this workgroup that take part in the launch
     uint64_t mask1;  // state_ops only (float flavour): second stream of each lane; chain launches ignore it
 };

@@ -10,8 +10,8 @@ namespace dspi {
 constexpr int kChunk = 16;   // frames per in-kernel chunk (divides the 48- and 96-frame packets)
 
 struct KArgs {
-    const DevImage *img;     // one image: every lane of this launch uses it (scalar loads)
-    const WgItem *items;     // workgroups (and lane masks) that belong to the image
+    const DevImage *img;     // the context's image array; a workgroup uses img[item.image] (scalar loads: its lanes share it)
+    const WgItem *items;     // workgroups of this launch: row, image, lane mask
     uint32_t *state;         // [n_wg][n_slots][64]
     uint32_t *dlines;        // [n_wg][n_out][max_delay][64]
     uint32_t *ring;          // [n_wg][kRingLen][2][64]
@@ -27,7 +27,7 @@ struct KArgs {
 size_t chain_lds_bytes(int flavor, int packed);
 // packed != 0 (float flavour only): items list lanes whose two streams are both processed (v_pk kernel);
 // packed == 0: scalar kernel, one stream per lane (float: the stream args.comp of each listed lane)
-// leveller_on: IF_LEVELLER_ON of args.img (the host knows it; the packed kernel is specialised on it)
+// leveller_on: IF_LEVELLER_ON of every image in args.items (the host groups them; the packed kernel is specialised on it)
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
                             uint32_t *ring, uint32_t n_streams, hipStream_t stream);

@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     // wave still reaches every barrier.
     asm volatile("s_mov_b64 exec, %0" ::"s"(item.mask) : "memory");
     constexpr bool active = true;
-    ImgPtr img = to_const(a.img);
+    ImgPtr img = to_const(a.img + item.image);
 
     uint32_t *gs = a.state + (size_t)wg * sm.n_slots * ROW + col;
     for (int s = wave; s < sm.lds_slots; s += 4) lds[s * kLanes + lane] = gs[(size_t)s * ROW];

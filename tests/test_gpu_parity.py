@@ -136,6 +136,33 @@ def test_per_stream_presets_and_clip_flags():
 
 
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+def test_many_presets_one_process_call(flavor):
+    """Dozens of parameter images in one context (every third stream its own preamp, some with the leveller off, some
+    muted): launches are grouped by leveller on/off, not by image, and every stream still matches its own oracle."""
+    fs, B, S, blocks = 48000, 48, 150, 8
+    d = Dspi(flavor, S, device=0); o = [Oracle(flavor, detmath=True) for _ in range(S)]
+    blob = WL.full_chain_blob(flavor)
+    for x in [d] + o:
+        x.set_rate(fs); x.set_volume(-8 * 256); x.load_bulk(blob)
+    for s_ in range(0, S, 3):
+        db = struct.pack("<f", -12.0 + 0.25 * s_)
+        d.vendor_set(W.REQ["SET_PREAMP"], 0, db, stream=s_); o[s_].vendor_set(W.REQ["SET_PREAMP"], 0, db)
+        if s_ % 2 == 0:
+            d.vendor_set(W.REQ["SET_LEVELLER_ENABLE"], 0, b"\x00", stream=s_); o[s_].vendor_set(W.REQ["SET_LEVELLER_ENABLE"], 0, b"\x00")
+        if s_ % 5 == 0:
+            d.vendor_set(W.REQ["SET_OUTPUT_MUTE"], 1, b"\x01", stream=s_); o[s_].vendor_set(W.REQ["SET_OUTPUT_MUTE"], 1, b"\x01")
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
+    for c in range(2):
+        chunk = np.ascontiguousarray(pcm[:, c * blocks * B:(c + 1) * blocks * B])
+        pairs, sub, peaks = d.process_host(chunk, blocks, B)
+        for s_ in range(S):
+            rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B)
+            assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (c, s_)
+            assert o[s_].status() == d.status(s_)
+    d.close()
+
+
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_tiled_output_layout(flavor):
     """DSPI_OUT_TILED ([tile][output][frame][R]) carries exactly the words of the stream-major layout: packed and
     one-stream kernels (two streams get their own preset), ragged last tile, tail packets on the second call."""
