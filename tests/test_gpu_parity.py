@@ -72,6 +72,14 @@ def test_full_chain(flavor, fs, B, depth):
 
 
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+def test_long_run_wraps_delay_lines(flavor):
+    """More frames than a delay line holds (4096 float / 2048 Q28 positions): the shared write index wraps, the 80 ms /
+    40 ms lines read across the wrap, and the leveller ring (1024) goes round several times; three launches."""
+    fs, B = (96000, 96) if flavor else (48000, 48)
+    compare(flavor, fs, B, 54, 6, WL.full_chain_blob(flavor), calls=3, first_stream=2)
+
+
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_host_volume_sign_quirk_and_mute(flavor):
     compare(flavor, 96000 if flavor else 48000, 96 if flavor else 48, 12, 6, WL.full_chain_blob(flavor), vol=0)
     compare(flavor, 48000, 48, 12, 3, WL.full_chain_blob(flavor), setup=lambda x: x.set_mute(True))
