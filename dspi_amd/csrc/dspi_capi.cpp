@@ -54,6 +54,10 @@ struct dspi_ctx {
     int32_t *d_pairs = nullptr; size_t d_pairs_cap = 0;
     int32_t *d_sub = nullptr; size_t d_sub_cap = 0;
     uint16_t *d_peaks = nullptr; size_t d_peaks_cap = 0;
+    // PDM sub output (dspi_pdm.hip): modulator state per stream, allocated on first use; staging for host buffers
+    uint32_t *d_pdm = nullptr;
+    int32_t *d_pdm_in = nullptr; size_t d_pdm_in_cap = 0;
+    uint32_t *d_pdm_out = nullptr; size_t d_pdm_out_cap = 0;
     std::string err;
 };
 
@@ -309,7 +313,7 @@ void dspi_destroy(dspi_ctx *c) {
     if (c->device != DSPI_DEVICE_NONE) {
         (void)hipSetDevice(c->device);
         if (c->hs) (void)hipStreamSynchronize(c->hs);
-        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, c->d_in,
+        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, c->d_in,
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
             if (p) (void)hipFree(p);
         if (c->hs) (void)hipStreamDestroy(c->hs);
@@ -401,6 +405,50 @@ int dspi_debug_image(dspi_ctx *c, int32_t stream, void *buf, size_t cap) {
     readable(c, stream).build_image(img);
     memcpy(buf, &img, sizeof(img));
     return (int)sizeof(img);
+}
+
+// ---- PDM sub output: pdm_generator.c:351-397 per sample (dspi_pdm.hip) ----
+static int pdm_state(dspi_ctx *c) {
+    if (c->d_pdm) return 0;
+    const size_t b = (size_t)c->n_wg * kPdmStateWords * c->sm.row * 4;
+    if (hipMalloc((void **)&c->d_pdm, b) != hipSuccess) return fail(c, DSPI_E_NOMEM, "hipMalloc failed (PDM state)");
+    HIPCK(c, hipMemsetAsync(c->d_pdm, 0, b, c->hs));
+    HIPCK(c, launch_pdm_reset(c->d_pdm, c->n_streams, (uint32_t)c->sm.row, c->n_wg, -1, 1, c->hs));
+    return 0;
+}
+
+int dspi_pdm_modulate(dspi_ctx *c, const int32_t *sub, uint32_t n_frames, uint32_t *words, uint32_t flags) {
+    if (!c || !sub || !words || n_frames == 0) return DSPI_E_INVAL;
+    if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = pdm_state(c);
+    if (rc) return rc;
+    const bool tiled = flags & DSPI_OUT_TILED, dev = flags & DSPI_MEM_DEVICE;
+    const size_t cols = tiled ? (size_t)c->n_wg * c->sm.row : (size_t)c->n_streams;
+    const size_t in_b = cols * n_frames * 4, out_b = in_b * 8;
+    const int32_t *d_in = sub;
+    uint32_t *d_out = words;
+    if (!dev) {
+        if ((rc = ensure(c, c->d_pdm_in, c->d_pdm_in_cap, in_b)) || (rc = ensure(c, c->d_pdm_out, c->d_pdm_out_cap, out_b))) return rc;
+        HIPCK(c, hipMemcpyAsync(c->d_pdm_in, sub, in_b, hipMemcpyHostToDevice, c->hs));
+        d_in = c->d_pdm_in; d_out = c->d_pdm_out;
+    }
+    HIPCK(c, launch_pdm(tiled, c->d_pdm, d_in, d_out, c->n_streams, n_frames, (uint32_t)c->sm.row, c->n_wg, c->hs));
+    if (!dev) {
+        HIPCK(c, hipMemcpyAsync(words, c->d_pdm_out, out_b, hipMemcpyDeviceToHost, c->hs));
+        HIPCK(c, hipStreamSynchronize(c->hs));
+    }
+    return DSPI_OK;
+}
+
+int dspi_pdm_restart(dspi_ctx *c, int32_t stream) {
+    if (!c || !valid_stream(c, stream)) return DSPI_E_INVAL;
+    if (c->device == DSPI_DEVICE_NONE) return DSPI_E_NODEVICE;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = pdm_state(c);
+    if (rc) return rc;
+    HIPCK(c, launch_pdm_reset(c->d_pdm, c->n_streams, (uint32_t)c->sm.row, c->n_wg, stream == DSPI_ALL_STREAMS ? -1 : stream, 0, c->hs));
+    return DSPI_OK;
 }
 
 int dspi_sync(dspi_ctx *c) {

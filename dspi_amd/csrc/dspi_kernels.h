@@ -33,4 +33,10 @@ hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, c
                             uint32_t *ring, uint32_t n_streams, hipStream_t stream);
 hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream);
 
+// ---- PDM sub output (dspi_pdm.hip): per-stream state [n_wg][kPdmStateWords][row]: err err2 x1 x2 y1 y2 err_acc rng fade_in_pos
+constexpr int kPdmStateWords = 9;
+hipError_t launch_pdm(bool tiled, uint32_t *state, const int32_t *sub, uint32_t *words, uint32_t n_streams, uint32_t n_frames, uint32_t row,
+                      uint32_t n_wg, hipStream_t stream);
+hipError_t launch_pdm_reset(uint32_t *state, uint32_t n_streams, uint32_t row, uint32_t n_wg, int32_t only_stream, int init, hipStream_t stream);
+
 }  // namespace dspi

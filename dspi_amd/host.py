@@ -63,6 +63,8 @@ def lib() -> C.CDLL:
     L.dspi_set_mute.argtypes = [vp, i32, C.c_int]
     L.dspi_set_sample_rate.argtypes = [vp, i32, u32]
     L.dspi_process.argtypes = [vp, vp, C.c_int, u32, u32, C.POINTER(_Out), u32]
+    L.dspi_pdm_modulate.argtypes = [vp, vp, u32, vp, u32]
+    L.dspi_pdm_restart.argtypes = [vp, C.c_int32]
     L.dspi_sync.argtypes = [vp]
     L.dspi_hip_stream.argtypes = [vp]
     L.dspi_hip_stream.restype = vp
@@ -197,6 +199,21 @@ class Dspi:
         """Zero-copy path: raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous, see sync()."""
         out = _Out(pairs_ptr or None, sub_ptr or None, peaks_ptr or None)
         self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE | (OUT_TILED if tiled else 0)), "process")
+
+    def pdm_host(self, sub: np.ndarray, tiled: bool = False) -> np.ndarray:
+        """PDM sub output (dspi_pdm_modulate) on host arrays: sub int32 [streams][frames] -> uint32 [streams][frames][8];
+        tiled: [tiles][frames][R] -> [tiles][frames][8][R]."""
+        sub = np.ascontiguousarray(sub, dtype=np.int32)
+        words = np.zeros(sub.shape[:2] + (8,) + sub.shape[2:], dtype=np.uint32)
+        n_frames = sub.shape[1]
+        self._ck(self.L.dspi_pdm_modulate(self.h, sub.ctypes.data, n_frames, words.ctypes.data, OUT_TILED if tiled else 0), "pdm_modulate")
+        return words
+
+    def pdm_device(self, sub_ptr: int, n_frames: int, words_ptr: int, tiled: bool = False):
+        self._ck(self.L.dspi_pdm_modulate(self.h, sub_ptr, n_frames, words_ptr, MEM_DEVICE | (OUT_TILED if tiled else 0)), "pdm_modulate")
+
+    def pdm_restart(self, stream: int = ALL):
+        self._ck(self.L.dspi_pdm_restart(self.h, stream), "pdm_restart")
 
     def sync(self):
         self._ck(self.L.dspi_sync(self.h), "sync")

@@ -129,6 +129,19 @@ int dspi_set_sample_rate(dspi_ctx *ctx, int32_t stream, uint32_t hz);           
 int dspi_process(dspi_ctx *ctx, const void *pcm_in, int bit_depth, uint32_t n_blocks, uint32_t block_len,
                  const dspi_out *out, uint32_t flags);
 int dspi_sync(dspi_ctx *ctx);
+
+/* ---- PDM sub output ---------------------------------------------------- */
+/* The consumer of dspi_out.sub: the firmware's 256x oversampled 2nd-order sigma-delta modulator with noise-shaped
+ * dither (pdm_generator.c:62-108, :351-397; the loop Core 1 runs in CORE1_MODE_PDM).  One stream = one modulator;
+ * its state (integrators, noise shaper, dither RNG, 1024-sample fade-in) lives in the context and carries across calls.
+ *   sub    int32 [stream][n_frames]        Q28, exactly what dspi_process wrote to dspi_out.sub
+ *   words  uint32 [stream][n_frames][8]    8 x 32 PDM bits per sample, MSB = first bit on the wire (the words the
+ *                                          firmware queues for its PIO/DMA)
+ * With DSPI_OUT_TILED: sub = [tile][n_frames][R], words = [tile][n_frames][8][R].  DSPI_MEM_DEVICE as in dspi_process.
+ * Not modelled: DMA ring pacing, under-run recovery and the fade-out on disable (transport, not sample arithmetic). */
+int dspi_pdm_modulate(dspi_ctx *ctx, const int32_t *sub, uint32_t n_frames, uint32_t *words, uint32_t flags);
+/* the re-enable path (pdm_generator.c:241-252): integrators, noise shaper and fade-in restart, the dither RNG runs on */
+int dspi_pdm_restart(dspi_ctx *ctx, int32_t stream);
 /* the HIP stream (hipStream_t) the context launches on, for event timing by the caller */
 void *dspi_hip_stream(dspi_ctx *ctx);
 

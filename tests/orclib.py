@@ -15,8 +15,8 @@ _libs: dict = {}
 
 
 def _build():
-    need = [ORC_DIR / "liborc_f32.so", ORC_DIR / "liborc_q28.so"]
-    srcs = [ORC_DIR / n for n in ("orc_chain.c", "orc_leaf.c", "orc_types.h", "orc_leaf.h", "orc_common.h", "orc_api.h")]
+    need = [ORC_DIR / "liborc_f32.so", ORC_DIR / "liborc_q28.so", ORC_DIR / "liborc_pdm.so"]
+    srcs = [ORC_DIR / n for n in ("orc_chain.c", "orc_leaf.c", "orc_types.h", "orc_leaf.h", "orc_common.h", "orc_api.h", "orc_pdm.c")]
     srcs.append(ROOT / "include" / "dspi_detmath.h")
     newest = max(s.stat().st_mtime for s in srcs)
     if all(p.exists() and p.stat().st_mtime >= newest for p in need):
@@ -159,3 +159,23 @@ class Oracle:
         self.lib.orc_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, pairs.ctypes.data, sub.ctypes.data,
                              peaks.ctypes.data if want_peaks else None, clip.ctypes.data)
         return pairs, sub, peaks, int(clip[0])
+
+
+class PdmOracle:
+    """One PDM sigma-delta modulator (oracle/orc_pdm.c): the consumer of the chain's Q28 sub output."""
+
+    def __init__(self):
+        _build()
+        self.L = C.CDLL(str(ORC_DIR / "liborc_pdm.so"), mode=os.RTLD_LOCAL)
+        self.L.orc_pdm_state_words.restype = C.c_int
+        self.st = (C.c_uint32 * self.L.orc_pdm_state_words())()
+        self.L.orc_pdm_init(self.st)
+
+    def restart(self):
+        self.L.orc_pdm_restart(self.st)
+
+    def run(self, sub: np.ndarray) -> np.ndarray:
+        sub = np.ascontiguousarray(sub, dtype=np.int32)
+        words = np.zeros((sub.size, 8), dtype=np.uint32)
+        self.L.orc_pdm_run(self.st, sub.ctypes.data_as(C.c_void_p), C.c_uint32(sub.size), words.ctypes.data_as(C.c_void_p))
+        return words

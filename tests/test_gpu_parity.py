@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import has_gpu
-from orclib import Oracle
+from orclib import Oracle, PdmOracle
 from dspi_amd import wire as W, workloads as WL
 from dspi_amd.host import Dspi
 
@@ -236,3 +236,34 @@ def test_full_size_properties():
         (rp, rs, _, _), _ = oracle_run(1, fs, -20 * 256, WL.full_chain_blob(1), base[idx[s]], blocks, B, 16)
         assert np.array_equal(rp, pairs[s].cpu().numpy()) and np.array_equal(rs, sub[s].cpu().numpy())
     d.close()
+
+
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+def test_pdm_sub_output(flavor):
+    """the sigma-delta consumer of the sub output (dspi_pdm_modulate) is bit-exact against the CPU
+    restatement: fed by the chain's own sub words, both layouts, state carried over three calls, restart of one stream,
+    inputs beyond the hard limiter."""
+    fs, B, blocks = 48000, 48, 10
+    S = 150 if flavor else 90
+    chain = Dspi(flavor, S, device=0); chain.set_rate(fs); chain.set_volume(-4 * 256); assert chain.load_bulk(WL.full_chain_blob(flavor)) == 0
+    pcm = WL.synth_pcm16(S, B * blocks * 3, fs)
+    d_sm, d_t = Dspi(flavor, S, device=0), Dspi(flavor, S, device=0)
+    o = [PdmOracle() for _ in range(S)]
+    rng = np.random.default_rng(5)
+    for c in range(3):
+        _, sub, _ = chain.process_host(np.ascontiguousarray(pcm[:, c * blocks * B:(c + 1) * blocks * B]), blocks, B)
+        sub = sub.copy()
+        sub[3] = rng.integers(-(1 << 30), 1 << 30, size=sub.shape[1], dtype=np.int64).astype(np.int32)     # beyond +-1.8: limiter
+        sub[7, ::5] = -(1 << 31)
+        if c == 2:
+            d_sm.pdm_restart(11); d_t.pdm_restart(11); o[11].restart()
+        w_sm = d_sm.pdm_host(sub)
+        R = d_t.tile_streams(); nt = (S + R - 1) // R
+        sub_t = np.zeros((nt * R, sub.shape[1]), dtype=np.int32); sub_t[:S] = sub
+        sub_t = np.ascontiguousarray(sub_t.reshape(nt, R, -1).transpose(0, 2, 1))
+        w_t = d_t.pdm_host(sub_t, tiled=True)                                  # [tile][frame][8][R]
+        w_t = w_t.transpose(0, 3, 1, 2).reshape(nt * R, sub.shape[1], 8)[:S]
+        assert np.array_equal(w_sm, w_t), c
+        for s_ in range(S):
+            assert np.array_equal(o[s_].run(sub[s_]), w_sm[s_]), (c, s_)
+    for x in (chain, d_sm, d_t): x.close()
