@@ -58,6 +58,8 @@ struct dspi_ctx {
     uint32_t *d_pdm = nullptr;
     int32_t *d_pdm_in = nullptr; size_t d_pdm_in_cap = 0;
     uint32_t *d_pdm_out = nullptr; size_t d_pdm_out_cap = 0;
+    int32_t *d_spdif_in = nullptr; size_t d_spdif_in_cap = 0;
+    uint32_t *d_spdif_out = nullptr; size_t d_spdif_out_cap = 0;
     std::string err;
 };
 
@@ -313,7 +315,7 @@ void dspi_destroy(dspi_ctx *c) {
     if (c->device != DSPI_DEVICE_NONE) {
         (void)hipSetDevice(c->device);
         if (c->hs) (void)hipStreamSynchronize(c->hs);
-        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, c->d_in,
+        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
             if (p) (void)hipFree(p);
         if (c->hs) (void)hipStreamDestroy(c->hs);
@@ -449,6 +451,31 @@ int dspi_pdm_restart(dspi_ctx *c, int32_t stream) {
     if (rc) return rc;
     HIPCK(c, launch_pdm_reset(c->d_pdm, c->n_streams, (uint32_t)c->sm.row, c->n_wg, stream == DSPI_ALL_STREAMS ? -1 : stream, 0, c->hs));
     return DSPI_OK;
+}
+
+// ---- S/PDIF subframes: pico_audio_spdif_multi sample_encoding.h:27-47 + audio_spdif.c:76-116 (dspi_spdif.hip) ----
+int dspi_spdif_encode(dspi_ctx *c, const int32_t *pairs, uint32_t n_frames, uint32_t block_pos, uint32_t *subframes, uint32_t flags) {
+    if (!c || !pairs || !subframes || n_frames == 0 || block_pos >= 192) return DSPI_E_INVAL;
+    if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
+    HIPCK(c, hipSetDevice(c->device));
+    const bool tiled = flags & DSPI_OUT_TILED, dev = flags & DSPI_MEM_DEVICE;
+    const size_t cols = tiled ? (size_t)c->n_wg * c->sm.row : (size_t)c->n_streams;
+    const size_t in_b = cols * c->sm.n_pairs * n_frames * 8, out_b = in_b * 2;
+    const int32_t *d_in = pairs;
+    uint32_t *d_out = subframes;
+    int rc;
+    if (!dev) {
+        if ((rc = ensure(c, c->d_spdif_in, c->d_spdif_in_cap, in_b)) || (rc = ensure(c, c->d_spdif_out, c->d_spdif_out_cap, out_b))) return rc;
+        HIPCK(c, hipMemcpyAsync(c->d_spdif_in, pairs, in_b, hipMemcpyHostToDevice, c->hs));
+        d_in = c->d_spdif_in; d_out = c->d_spdif_out;
+    }
+    const uint32_t fs = readable(c, DSPI_ALL_STREAMS).freq;
+    HIPCK(c, launch_spdif(tiled, d_in, d_out, c->n_streams, (uint32_t)c->sm.n_pairs, n_frames, (uint32_t)c->sm.row, c->n_wg, block_pos, fs, c->hs));
+    if (!dev) {
+        HIPCK(c, hipMemcpyAsync(subframes, c->d_spdif_out, out_b, hipMemcpyDeviceToHost, c->hs));
+        HIPCK(c, hipStreamSynchronize(c->hs));
+    }
+    return (int)((block_pos + n_frames) % 192u);
 }
 
 int dspi_sync(dspi_ctx *c) {

@@ -39,4 +39,8 @@ hipError_t launch_pdm(bool tiled, uint32_t *state, const int32_t *sub, uint32_t 
                       uint32_t n_wg, hipStream_t stream);
 hipError_t launch_pdm_reset(uint32_t *state, uint32_t n_streams, uint32_t row, uint32_t n_wg, int32_t only_stream, int init, hipStream_t stream);
 
+// ---- S/PDIF subframe encoder (dspi_spdif.hip)
+hipError_t launch_spdif(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
+                        uint32_t n_wg, uint32_t block_pos, uint32_t fs, hipStream_t stream);
+
 }  // namespace dspi

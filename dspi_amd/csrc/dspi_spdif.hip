@@ -1,0 +1,109 @@
+// dspi_spdif.hip — IEC 60958 (S/PDIF) subframe encoding of the chain's int24 pair words on the GPU.
+//
+// Reference: firmware/pico-extras/src/rp2_common/pico_audio_spdif_multi/ — what DSPi's S/PDIF outputs do to the words
+// of dspi_out.pairs before the PIO shifts them out:
+//   spdif_update_subframe           include/pico/audio_spdif/sample_encoding.h:27-47 (three byte look-ups, parity)
+//   byte table                      audio_spdif.c:141-153 (every data bit b becomes the cell pair "1 b": 0x5555 | b<<(2j+1))
+//   preambles / channel status      audio_spdif.c:76-94, :101-116, sample-rate byte :250-256, block restamp :385-405
+// A frame's two subframes (4 words) are a pure function of (left word, right word, position in the 192-frame block,
+// sample rate), so this is byte shuffling at memory speed: 8 bytes in, 16 bytes out per frame and pair.  The byte table
+// is replaced by the bit spread it tabulates (three shift/or/and steps), so there is no LDS gather.
+//
+// Mapping: workgroup = (tile row of the context, pair), lane = stream; with the tiled layouts every access is one
+// coalesced row: in [tile][output][frame][R], out [tile][pair][frame][4][R].
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dspi_kernels.h"
+
+namespace dspi {
+
+namespace {
+
+// spdif_lookup[b] (audio_spdif.c:141-153): low 16 bits = 0x5555 | (bit j of b) << (2j+1), bit 16 = parity of b
+__device__ __forceinline__ uint32_t bmc_byte(uint32_t b) {
+    uint32_t x = b & 0xffu;
+    x = (x | (x << 4)) & 0x0f0fu;
+    x = (x | (x << 2)) & 0x3333u;
+    x = (x | (x << 1)) & 0x5555u;
+    return 0x5555u | (x << 1) | ((uint32_t)(__builtin_popcount(b & 0xffu) & 1) << 16);
+}
+
+// spdif_update_subframe on a pre-filled subframe {preamble, 0x55000000 | c << 29} (sample_encoding.h:27-47)
+__device__ __forceinline__ void subframe(uint32_t sample, uint32_t preamble, uint32_t c_bit, uint32_t &l, uint32_t &h) {
+    const uint32_t s0 = bmc_byte(sample), s1 = bmc_byte(sample >> 8), s2 = bmc_byte(sample >> 16);
+    l = preamble | ((s0 & 0xffffu) << 8) | (s1 << 24);
+    const uint32_t ph = 0x55u | (c_bit << 5);
+    uint32_t p = (s0 >> 16) ^ (s1 >> 16) ^ (s2 >> 16);
+    p ^= (((ph & 0x2au) * 0x2au) >> 6) & 1u;
+    h = ((s1 & 0xffffu) >> 8) | ((s2 & 0xffffu) << 8) | ((ph & 0x7fu) << 24) | (p << 31);
+}
+
+constexpr uint32_t kFrameSlice = 32;
+
+template <bool TILED>
+__global__ __launch_bounds__(128) void spdif_kernel(const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames,
+                                                     uint32_t row, uint32_t block_pos, uint32_t status_lo, uint32_t status_hi) {
+    const uint32_t wg = blockIdx.x, pair = blockIdx.y, col = threadIdx.x;
+    const uint32_t stream = wg * row + col;
+    if (col >= row || stream >= n_streams) return;
+    const size_t F = n_frames;
+    // tiled: outputs 2*pair and 2*pair+1 are separate [frame][R] planes; stream-major: interleaved [frame][2]
+    const int32_t *inL = TILED ? pairs + ((size_t)wg * (2 * n_pairs) + 2 * pair) * F * row + col : pairs + ((size_t)stream * n_pairs + pair) * F * 2;
+    const int32_t *inR = TILED ? inL + F * row : inL + 1;
+    const size_t in_step = TILED ? row : 2;
+    uint32_t *o = TILED ? out + ((size_t)wg * n_pairs + pair) * F * 4 * row + col : out + ((size_t)stream * n_pairs + pair) * F * 4;
+    // frames are independent: blockIdx.z takes a slice of kFrameSlice frames so that thousands of waves stream at once
+    const uint32_t f0 = blockIdx.z * kFrameSlice, f1 = min(n_frames, f0 + kFrameSlice);
+    uint32_t pos = (block_pos + f0) % 192u;
+    for (uint32_t f = f0; f < f1; ++f) {
+        const uint32_t wl = (uint32_t)inL[(size_t)f * in_step], wr = (uint32_t)inR[(size_t)f * in_step];
+        // channel status bit of this block position (40 bits, the rest zero): audio_spdif.c:91-94
+        const uint32_t c_bit = pos < 32 ? (status_lo >> pos) & 1u : (pos < 40 ? (status_hi >> (pos - 32)) & 1u : 0u);
+        uint32_t l0, h0, l1, h1;
+        subframe(wl, pos == 0 ? 0x39u : 0xC9u, c_bit, l0, h0);      // PREAMBLE_Z at the block start, else PREAMBLE_X
+        subframe(wr, 0x69u, c_bit, l1, h1);                          // PREAMBLE_Y
+        if (TILED) {
+            uint32_t *q = o + (size_t)f * 4 * row;
+            q[0] = l0; q[row] = h0; q[2 * row] = l1; q[3 * row] = h1;
+        } else {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u4 *>(o + (size_t)f * 4) = u4{l0, h0, l1, h1};
+        }
+        pos = (pos + 1 == 192u) ? 0u : pos + 1;
+    }
+}
+
+// Stream-major buffers are contiguous in time per (stream, pair), and a frame's subframes depend on nothing but its own
+// words and its block position: one lane per FRAME here, so a wave reads 512 and writes 1024 contiguous bytes.
+__global__ __launch_bounds__(256) void spdif_kernel_frames(const int32_t *pairs, uint32_t *out, uint64_t total, uint32_t n_frames, uint32_t block_pos,
+                                                          uint32_t status_lo, uint32_t status_hi) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;      // (stream * n_pairs + pair) * n_frames + frame
+    if (idx >= total) return;
+    const uint32_t f = (uint32_t)(idx % n_frames);
+    const uint32_t pos = (block_pos + f) % 192u;
+    const uint32_t wl = (uint32_t)pairs[idx * 2], wr = (uint32_t)pairs[idx * 2 + 1];
+    const uint32_t c_bit = pos < 32 ? (status_lo >> pos) & 1u : (pos < 40 ? (status_hi >> (pos - 32)) & 1u : 0u);
+    uint32_t l0, h0, l1, h1;
+    subframe(wl, pos == 0 ? 0x39u : 0xC9u, c_bit, l0, h0);
+    subframe(wr, 0x69u, c_bit, l1, h1);
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<u4 *>(out + idx * 4) = u4{l0, h0, l1, h1};
+}
+
+}  // namespace
+
+hipError_t launch_spdif(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
+                        uint32_t n_wg, uint32_t block_pos, uint32_t fs, hipStream_t stream) {
+    // IEC 60958-3 consumer channel status, 5 bytes (audio_spdif.c:83-89, sample-rate byte :250-256)
+    const uint32_t rate = fs == 44100 ? 0x00u : fs == 48000 ? 0x02u : fs == 96000 ? 0x0Au : 0x01u;
+    const uint32_t lo = 0x04u | (rate << 24), hi = 0x0Bu;
+    if (tiled) hipLaunchKernelGGL(spdif_kernel<true>, dim3(n_wg, n_pairs, (n_frames + kFrameSlice - 1) / kFrameSlice), dim3(128), 0, stream, pairs, out, n_streams, n_pairs, n_frames, row, block_pos, lo, hi);
+    else {
+        const uint64_t total = (uint64_t)n_streams * n_pairs * n_frames;
+        hipLaunchKernelGGL(spdif_kernel_frames, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pairs, out, total, n_frames, block_pos, lo, hi);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dspi

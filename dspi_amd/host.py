@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
     L.dspi_process.argtypes = [vp, vp, C.c_int, u32, u32, C.POINTER(_Out), u32]
     L.dspi_pdm_modulate.argtypes = [vp, vp, u32, vp, u32]
     L.dspi_pdm_restart.argtypes = [vp, C.c_int32]
+    L.dspi_spdif_encode.argtypes = [vp, vp, u32, u32, vp, u32]
     L.dspi_sync.argtypes = [vp]
     L.dspi_hip_stream.argtypes = [vp]
     L.dspi_hip_stream.restype = vp
@@ -211,6 +212,25 @@ class Dspi:
 
     def pdm_device(self, sub_ptr: int, n_frames: int, words_ptr: int, tiled: bool = False):
         self._ck(self.L.dspi_pdm_modulate(self.h, sub_ptr, n_frames, words_ptr, MEM_DEVICE | (OUT_TILED if tiled else 0)), "pdm_modulate")
+
+    def spdif_host(self, pairs: np.ndarray, block_pos: int = 0, tiled: bool = False):
+        """S/PDIF subframes (dspi_spdif_encode) on host arrays: pairs int32 [streams][P][frames][2] -> uint32
+        [streams][P][frames][4]; tiled: [tiles][2P][frames][R] -> [tiles][P][frames][4][R].  Returns (subframes, next_pos)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+        if tiled:
+            nt, O, F, R = pairs.shape
+            out = np.zeros((nt, O // 2, F, 4, R), dtype=np.uint32)
+        else:
+            S, P, F, _ = pairs.shape
+            out = np.zeros((S, P, F, 4), dtype=np.uint32)
+        nxt = self.L.dspi_spdif_encode(self.h, pairs.ctypes.data, F, block_pos, out.ctypes.data, OUT_TILED if tiled else 0)
+        self._ck(min(nxt, 0), "spdif_encode")
+        return out, nxt
+
+    def spdif_device(self, pairs_ptr: int, n_frames: int, block_pos: int, out_ptr: int, tiled: bool = False) -> int:
+        nxt = self.L.dspi_spdif_encode(self.h, pairs_ptr, n_frames, block_pos, out_ptr, MEM_DEVICE | (OUT_TILED if tiled else 0))
+        self._ck(min(nxt, 0), "spdif_encode")
+        return nxt
 
     def pdm_restart(self, stream: int = ALL):
         self._ck(self.L.dspi_pdm_restart(self.h, stream), "pdm_restart")

@@ -142,6 +142,18 @@ int dspi_sync(dspi_ctx *ctx);
 int dspi_pdm_modulate(dspi_ctx *ctx, const int32_t *sub, uint32_t n_frames, uint32_t *words, uint32_t flags);
 /* the re-enable path (pdm_generator.c:241-252): integrators, noise shaper and fade-in restart, the dither RNG runs on */
 int dspi_pdm_restart(dspi_ctx *ctx, int32_t stream);
+
+/* ---- S/PDIF subframes ---------------------------------------------------- */
+/* What the firmware's S/PDIF outputs do to the words of dspi_out.pairs before the PIO shifts them out
+ * (pico_audio_spdif_multi: spdif_update_subframe, sample_encoding.h:27-47; preambles Z/X/Y, consumer channel status with
+ * the sample-rate byte of stream 0's current rate, 192-frame block position: audio_spdif.c:76-116, :250-256, :385-405).
+ *   pairs      int32 [stream][pair][n_frames][2]       exactly what dspi_process wrote
+ *   subframes  uint32 [stream][pair][n_frames][4]      {l, h} of the left subframe, {l, h} of the right one: the 16 bytes
+ *                                                      the firmware's DMA buffer holds per stereo frame
+ * With DSPI_OUT_TILED: pairs = [tile][output][n_frames][R], subframes = [tile][pair][n_frames][4][R].
+ * block_pos = position of the first frame in the 192-frame channel-status block (0..191).  Returns the position that
+ * follows the last frame (>= 0; feed it to the next call) or a negative DSPI_E_*. */
+int dspi_spdif_encode(dspi_ctx *ctx, const int32_t *pairs, uint32_t n_frames, uint32_t block_pos, uint32_t *subframes, uint32_t flags);
 /* the HIP stream (hipStream_t) the context launches on, for event timing by the caller */
 void *dspi_hip_stream(dspi_ctx *ctx);
 

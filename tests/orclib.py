@@ -15,8 +15,8 @@ _libs: dict = {}
 
 
 def _build():
-    need = [ORC_DIR / "liborc_f32.so", ORC_DIR / "liborc_q28.so", ORC_DIR / "liborc_pdm.so"]
-    srcs = [ORC_DIR / n for n in ("orc_chain.c", "orc_leaf.c", "orc_types.h", "orc_leaf.h", "orc_common.h", "orc_api.h", "orc_pdm.c")]
+    need = [ORC_DIR / "liborc_f32.so", ORC_DIR / "liborc_q28.so", ORC_DIR / "liborc_pdm.so", ORC_DIR / "liborc_spdif.so"]
+    srcs = [ORC_DIR / n for n in ("orc_chain.c", "orc_leaf.c", "orc_types.h", "orc_leaf.h", "orc_common.h", "orc_api.h", "orc_pdm.c", "orc_spdif.c")]
     srcs.append(ROOT / "include" / "dspi_detmath.h")
     newest = max(s.stat().st_mtime for s in srcs)
     if all(p.exists() and p.stat().st_mtime >= newest for p in need):
@@ -179,3 +179,18 @@ class PdmOracle:
         words = np.zeros((sub.size, 8), dtype=np.uint32)
         self.L.orc_pdm_run(self.st, sub.ctypes.data_as(C.c_void_p), C.c_uint32(sub.size), words.ctypes.data_as(C.c_void_p))
         return words
+
+
+def spdif_ref_available() -> bool:
+    return (ORC_DIR / "_ref" / "libref_spdif.so").exists()
+
+
+def spdif_encode(pair_words: np.ndarray, block_pos: int, fs: int, ref: bool = False):
+    """oracle/orc_spdif.c: int32 [frames][2] -> uint32 [frames][4] ({l,h} left, {l,h} right), next block position."""
+    _build()
+    L = C.CDLL(str(ORC_DIR / ("_ref/libref_spdif.so" if ref else "liborc_spdif.so")), mode=os.RTLD_LOCAL)
+    L.orc_spdif_encode.restype = C.c_uint32
+    x = np.ascontiguousarray(pair_words, dtype=np.int32)
+    out = np.zeros((x.shape[0], 4), dtype=np.uint32)
+    nxt = L.orc_spdif_encode(x.ctypes.data_as(C.c_void_p), C.c_uint32(x.shape[0]), C.c_uint32(block_pos), C.c_uint32(fs), out.ctypes.data_as(C.c_void_p))
+    return out, int(nxt)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import has_gpu
+import orclib
 from orclib import Oracle, PdmOracle
 from dspi_amd import wire as W, workloads as WL
 from dspi_amd.host import Dspi
@@ -267,3 +268,34 @@ def test_pdm_sub_output(flavor):
         for s_ in range(S):
             assert np.array_equal(o[s_].run(sub[s_]), w_sm[s_]), (c, s_)
     for x in (chain, d_sm, d_t): x.close()
+
+
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+def test_spdif_subframes(flavor):
+    """S/PDIF subframe encoding of the chain's own pair words (dspi_spdif_encode) is bit-exact against the
+    oracle (which is pinned to the reference's spdif_update_subframe): both layouts, block position carried over calls,
+    all three sample rates."""
+    B, blocks = 48, 9                                # 432 frames: crosses the 192-frame block twice
+    S = 140 if flavor else 70
+    for fs in (48000, 96000, 44100):
+        d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-3 * 256); assert d.load_bulk(WL.full_chain_blob(flavor)) == 0
+        dt = Dspi(flavor, S, device=0); dt.set_rate(fs)
+        pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
+        pos = 5
+        for c in range(2):
+            pairs, _, _ = d.process_host(np.ascontiguousarray(pcm[:, c * blocks * B:(c + 1) * blocks * B]), blocks, B)
+            sf, nxt = d.spdif_host(pairs, pos)
+            R = dt.tile_streams(); nt = (S + R - 1) // R
+            P, F = pairs.shape[1], pairs.shape[2]
+            pt = np.zeros((nt * R, 2 * P, F), dtype=np.int32)
+            pt[:S] = pairs.transpose(0, 1, 3, 2).reshape(S, 2 * P, F)
+            pt = np.ascontiguousarray(pt.reshape(nt, R, 2 * P, F).transpose(0, 2, 3, 1))
+            sft, nxt_t = dt.spdif_host(pt, pos, tiled=True)                       # [tile][pair][frame][4][R]
+            sft = sft.transpose(0, 4, 1, 2, 3).reshape(nt * R, P, F, 4)[:S]
+            assert nxt == nxt_t == (pos + F) % 192 and np.array_equal(sf, sft)
+            for s_ in (0, 1, S // 2, S - 1):
+                for p_ in range(P):
+                    ref, n2 = orclib.spdif_encode(pairs[s_, p_], pos, fs)
+                    assert n2 == nxt and np.array_equal(ref, sf[s_, p_]), (fs, c, s_, p_)
+            pos = nxt
+        d.close(); dt.close()
