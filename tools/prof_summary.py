@@ -8,7 +8,7 @@ import glob, json, os, sqlite3, sys
 src, dst = sys.argv[1], sys.argv[2]
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 lines = [f"# rocprofv3 summary: {os.path.basename(src)}", "", note, "",
-         "Command profiled: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (config 3: 65 536 streams x 25 packets x 96 frames per launch = 157 286 400 frames/launch)", ""]
+         "Commands profiled: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (kernel trace) and `--steps 3 --warmup 1` (each PMC pass); config 3: 65 536 streams x 25 packets x 96 frames per launch = 157 286 400 frames/launch)", ""]
 tr = os.path.join(src, "trace", "trace_results.db")
 kernel_avg_us = None
 if os.path.exists(tr):
