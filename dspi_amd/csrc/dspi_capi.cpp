@@ -13,6 +13,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/dspi.h"
@@ -40,6 +41,7 @@ struct dspi_ctx {
     std::vector<WgItem> launch_items[2][4];
     uint32_t launch_item_offset[2][4] = {};
     WgItem *d_litems = nullptr; size_t d_litems_cap = 0;
+    uint32_t *d_stream_image = nullptr; size_t d_stream_image_cap = 0;   // image index per stream (per-lane parameter kernel)
     bool launch_dirty = true;
     // device
     hipStream_t hs = nullptr;
@@ -164,28 +166,43 @@ int rebuild_assignment(dspi_ctx *c) {
 }
 
 int rebuild_launch_lists(dspi_ctx *c) {
+    // lists 0 (Q28) and 1 (float lanes whose two streams share an image): one item per (row, image), grouped by leveller
+    // on/off for the float kernel variants.  Lists 2 / 3 (float lanes with ONE stream of an image, first / second
+    // stream): the one-stream float kernel reads every lane's own image, so all images of a row merge into one item.
     size_t total = 0;
     for (int lev = 0; lev < 2; lev++)
         for (int k = 0; k < 4; k++) {
             auto &v = c->launch_items[lev][k];
             v.clear();
-            for (size_t i = 0; i < c->images.size(); i++) {
-                if (c->image_refs[i] == 0) continue;
-                const int ilev = (c->flavor && (c->image_flags[i] & IF_LEVELLER_ON)) ? 1 : 0;
-                if (ilev != lev) continue;
-                for (WgItem it : c->image_items[k][i]) { it.image = (uint32_t)i; v.push_back(it); }
+            if (k >= 2) {
+                if (lev == 0) {
+                    std::map<uint32_t, uint64_t> rows;
+                    for (size_t i = 0; i < c->images.size(); i++)
+                        if (c->image_refs[i] > 0)
+                            for (const WgItem &it : c->image_items[k][i]) rows[it.wg] |= it.mask;
+                    for (const auto &r : rows) v.push_back(WgItem{r.first, 0u, r.second, 0ull});
+                }
+            } else {
+                for (size_t i = 0; i < c->images.size(); i++) {
+                    if (c->image_refs[i] == 0) continue;
+                    const int ilev = (c->flavor && (c->image_flags[i] & IF_LEVELLER_ON)) ? 1 : 0;
+                    if (ilev != lev) continue;
+                    for (WgItem it : c->image_items[k][i]) { it.image = (uint32_t)i; v.push_back(it); }
+                }
             }
             c->launch_item_offset[lev][k] = (uint32_t)total;
             total += v.size();
         }
     int rc = ensure(c, c->d_litems, c->d_litems_cap, total * sizeof(WgItem));
     if (rc) return rc;
-    HIPCK(c, hipStreamSynchronize(c->hs));      // no launch may still be reading the list we overwrite
+    if ((rc = ensure(c, c->d_stream_image, c->d_stream_image_cap, (size_t)c->n_streams * 4))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->hs));      // no launch may still be reading the lists we overwrite
     for (int lev = 0; lev < 2; lev++)
         for (int k = 0; k < 4; k++)
             if (!c->launch_items[lev][k].empty())
                 HIPCK(c, hipMemcpy(c->d_litems + c->launch_item_offset[lev][k], c->launch_items[lev][k].data(),
                                    c->launch_items[lev][k].size() * sizeof(WgItem), hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->d_stream_image, c->stream_image.data(), (size_t)c->n_streams * 4, hipMemcpyHostToDevice));
     c->launch_dirty = false;
     return 0;
 }
@@ -315,7 +332,7 @@ void dspi_destroy(dspi_ctx *c) {
     if (c->device != DSPI_DEVICE_NONE) {
         (void)hipSetDevice(c->device);
         if (c->hs) (void)hipStreamSynchronize(c->hs);
-        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
+        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_stream_image, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
             if (p) (void)hipFree(p);
         if (c->hs) (void)hipStreamDestroy(c->hs);
@@ -518,6 +535,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         if (out->peaks) { if ((rc = ensure(c, c->d_peaks, c->d_peaks_cap, peaks_b))) return rc; a.peaks = c->d_peaks; }
     }
     a.img = c->d_images;
+    a.stream_image = c->d_stream_image;
     // float flavour: lanes with both streams on one image go to the packed kernel (list 1), lanes with one stream of an
     // image to the one-stream kernel per component (lists 2, 3); Q28: the one-stream kernel over list 0.  One launch
     // per (leveller on/off, list) covers every image.

@@ -21,6 +21,7 @@ struct KArgs {
     uint16_t *peaks;         // [stream][block][C] or null
     uint32_t n_streams, n_blocks, block_len, bit_depth;
     uint32_t comp;           // float flavour, scalar kernel: which of a lane's two streams (column = lane*2 + comp)
+    const uint32_t *stream_image;   // [n_streams] image index of every stream (float one-stream kernel: per-lane parameters)
     uint32_t tiled_out;      // DSPI_OUT_TILED: pairs = [tile][output][frames][row], sub = [tile][frames][row] (row = StateMap::row)
 };
 

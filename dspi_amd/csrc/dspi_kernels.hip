@@ -154,6 +154,30 @@ __device__ __forceinline__ void run_bands(float (&x)[T], int n, BandPtr bands, f
     else run_bands16<NB, SHELF_ONLY>(x, bands, st);
 }
 
+// Per-lane parameters (the one-stream float kernel): every lane reads ITS stream's DevImage, so coefficients are vector
+// loads into VGPRs and the band kind is a per-lane value — the switch below is ordinary SIMT divergence (lanes of one kind
+// run together, kinds one after the other).  Same arithmetic, same order.
+template <bool TAIL, int NB, bool SHELF_ONLY = false>
+__device__ __forceinline__ void run_bands(float (&x)[T], int n, const DevBand *bands, float *__restrict__ st) {
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t kind = bands[b].kind;
+        if (kind == K_BYPASS) continue;
+        const float c0 = bands[b].c[0].f, c1 = bands[b].c[1].f, c2 = bands[b].c[2].f, c3 = bands[b].c[3].f, c4 = bands[b].c[4].f, c5 = bands[b].c[5].f;
+        float s1 = st[b * 2 * kLanes], s2 = st[b * 2 * kLanes + kLanes];
+        if (SHELF_ONLY) band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5);
+        else switch (kind) {
+            case K_BIQUAD: band_loop_f32<TAIL, K_BIQUAD>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            case K_SVF_LP: band_loop_f32<TAIL, K_SVF_LP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            case K_SVF_HP: band_loop_f32<TAIL, K_SVF_HP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            case K_SVF_PK: band_loop_f32<TAIL, K_SVF_PK>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            default: band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+        }
+        st[b * 2 * kLanes] = s1;
+        st[b * 2 * kLanes + kLanes] = s2;
+    }
+}
+
 // soft-knee upward gain computer, leveller.c:124-139
 __device__ __forceinline__ float gain_computer(float x_db, float thr, float ratio, float knee) {
     float half = knee * 0.5f;
@@ -166,7 +190,8 @@ __device__ __forceinline__ float gain_computer(float x_db, float thr, float rati
 }
 
 // per-packet gain decision, leveller.c:174-206 (float) == :304-332 (Q28); libm -> dspi_detmath.h
-__device__ __forceinline__ float leveller_block_gain(ImgPtr img, float &gsm_db, float rms_sq, uint32_t count) {
+template <class IMG>
+__device__ __forceinline__ float leveller_block_gain(IMG img, float &gsm_db, float rms_sq, uint32_t count) {
     float rms_db = 10.0f * dspi_det_log10f(rms_sq + 1e-30f);
     float gc;
     if (rms_db < img->lv_gate_db) gc = 0.0f;
@@ -227,8 +252,12 @@ struct MasterF32 {
     uint32_t pre_valid;
 };
 
+// The float one-stream kernel runs with PER-LANE parameter images (img is a per-lane pointer): it serves exactly the lanes
+// whose neighbours carry different presets.  Consequences: every `img->` read is a vector load, every parameter test is
+// SIMT divergence, and the step schedule cannot depend on a lane's flags — so every lane's samples travel through the ring
+// (one packet late), whether its leveller is on or not; a leveller that is off just copies them through.
 template <bool TAIL>
-__device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g,
+__device__ __forceinline__ void master_step_f32(const KArgs &a, const DevImage *img, const StateMap &sm, const Geo &g,
                                                 MasterF32 &m, float *__restrict__ lds_state, float *__restrict__ xch_base,
                                                 uint32_t wg, uint32_t lane, uint32_t col, uint32_t stream, bool active,
                                                 bool do_p1, uint32_t k1, uint32_t c1, bool do_item, uint32_t kq, uint32_t cq, uint32_t q) {
@@ -242,12 +271,12 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
     // Pass-2 operands come out of the ring (written >= one packet ago): issue those loads first so
     // they are in flight underneath the pass-1 arithmetic below.
     float ol[T], orr[T];
-    if (lev_on && do_item) {
-        if (cq == 0) {   // latch the ramp of packet kq before pass 1 below can decide the next packet's gain
+    if (do_item) {
+        if (lev_on && cq == 0) {   // latch the ramp of packet kq before pass 1 below can decide the next packet's gain
             if (g.B == 1) { m.p2_gain = m.g_cur; m.p2_step = 0.0f; }
             else { m.p2_step = (m.g_cur - m.g_prev) / (float)(g.B - 1); m.p2_gain = m.g_prev; }
         }
-        const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
+        const uint32_t back = (lev_on && (flags & IF_LOOKAHEAD)) ? (uint32_t)kLookahead : 0u;
         const uint32_t base = (m.rp2 + cq * T - back) & (kRingLen - 1);
         if (__all(base + T <= (uint32_t)kRingLen)) {          // no wrap inside the chunk: one base + immediate offsets
             const uint32_t *rl = ring + (size_t)base * ROW;
@@ -324,15 +353,15 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
             }
         }
         // ---- loudness shelves (usb_audio.c:688-718) ----
-        run_bands<TAIL, 2, true>(xl, n, img->loud, lds_state + (sm.loud + 0) * kLanes + lane);
-        run_bands<TAIL, 2, true>(xr, n, img->loud, lds_state + (sm.loud + 4) * kLanes + lane);
+        run_bands<TAIL, 2, true>(xl, n, &img->loud[0], lds_state + (sm.loud + 0) * kLanes + lane);
+        run_bands<TAIL, 2, true>(xr, n, &img->loud[0], lds_state + (sm.loud + 4) * kLanes + lane);
         // ---- PASS 2: master EQ (usb_audio.c:721-728) ----
         if (!(flags & IF_BYPASS_MASTER_EQ)) {
-            if (!(img->ch_bypassed & 1u)) run_bands<TAIL, kBands>(xl, n, img->eq[0], lds_state + (sm.eq + 0) * kLanes + lane);
-            if (!(img->ch_bypassed & 2u)) run_bands<TAIL, kBands>(xr, n, img->eq[1], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
+            if (!(img->ch_bypassed & 1u)) run_bands<TAIL, kBands>(xl, n, &img->eq[0][0], lds_state + (sm.eq + 0) * kLanes + lane);
+            if (!(img->ch_bypassed & 2u)) run_bands<TAIL, kBands>(xr, n, &img->eq[1][0], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
         }
-        if (lev_on) {
-            // ---- leveller pass 1: RMS envelopes (leveller.c:155-172), samples parked in the ring ----
+        {
+            // ---- leveller pass 1: RMS envelopes (leveller.c:155-172); every lane parks its samples in the ring ----
             const float ar = img->lv_alpha_rms, nar = 1.0f - ar;
             const uint32_t base = (m.rp1 + c1 * T) & (kRingLen - 1);
             const bool flat = __all(base + T <= (uint32_t)kRingLen);
@@ -340,8 +369,10 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
-                m.env_l = ar * m.env_l + nar * (xl[i] * xl[i]);
-                m.env_r = ar * m.env_r + nar * (xr[i] * xr[i]);
+                if (lev_on) {
+                    m.env_l = ar * m.env_l + nar * (xl[i] * xl[i]);
+                    m.env_r = ar * m.env_r + nar * (xr[i] * xr[i]);
+                }
                 if (active) {
                     if (flat) { wl[i * ROW] = as_u(xl[i]); wl[(kRingLen + i) * ROW] = as_u(xr[i]); }
                     else {
@@ -352,12 +383,14 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
                 }
             }
             if (c1 == g.cpb - 1) {   // end of packet: gain decision (leveller.c:168-206)
-                if (m.env_l < 1e-30f) m.env_l = 0.0f;
-                if (m.env_r < 1e-30f) m.env_r = 0.0f;
-                float rms_sq = (m.env_l > m.env_r) ? m.env_l : m.env_r;
-                float gn = leveller_block_gain(img, m.gsm_db, rms_sq, g.B);
-                m.g_prev = m.g_cur;
-                m.g_cur = gn;
+                if (lev_on) {
+                    if (m.env_l < 1e-30f) m.env_l = 0.0f;
+                    if (m.env_r < 1e-30f) m.env_r = 0.0f;
+                    float rms_sq = (m.env_l > m.env_r) ? m.env_l : m.env_r;
+                    float gn = leveller_block_gain(img, m.gsm_db, rms_sq, g.B);
+                    m.g_prev = m.g_cur;
+                    m.g_cur = gn;
+                }
                 m.rp1 = (m.rp1 + g.B) & (kRingLen - 1);
             }
         }
@@ -382,8 +415,11 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, ImgPtr img, cons
             xr[i] = orr[i] * gg;
             m.p2_gain += m.p2_step;
         }
-        if (cq == g.cpb - 1) m.rp2 = (m.rp2 + g.B) & (kRingLen - 1);
+    } else {      // leveller bypassed (usb_audio.c:731-738): the samples pass through untouched
+#pragma unroll
+        for (int i = 0; i < T; ++i) { if (TAIL && i >= nq) break; xl[i] = ol[i]; xr[i] = orr[i]; }
     }
+    if (cq == g.cpb - 1) m.rp2 = (m.rp2 + g.B) & (kRingLen - 1);
 
     // ---- PASS 3: master peaks (pre-crossfeed) + crossfeed (usb_audio.c:741-749, crossfeed.c:132-156) ----
     if (cq == 0) { m.pk_l = 0.0f; m.pk_r = 0.0f; }
@@ -439,7 +475,7 @@ struct OutF32 {
 };
 
 template <bool TAIL>
-__device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g,
+__device__ __forceinline__ void output_item_f32(const KArgs &a, const DevImage *img, const StateMap &sm, const Geo &g,
                                                 OutF32 &s, float *__restrict__ lds_state, float *__restrict__ lds_pk, const float *__restrict__ xch_base,
                                                 uint32_t wg, uint32_t lane, uint32_t col, uint32_t stream, bool active,
                                                 int o_first, int o_count, uint32_t kq, uint32_t cq, uint32_t q) {
@@ -532,7 +568,7 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, ImgPtr img, cons
             if (enabled) {
                 const int ch = 2 + o;
                 if (!muted && !((img->ch_bypassed >> ch) & 1u))
-                    run_bands<TAIL, kBands>(x, n, img->eq[ch], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
+                    run_bands<TAIL, kBands>(x, n, &img->eq[ch][0], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
                 float gain = muted ? 0.0f : img->out_gain_lin[o] * s.vmm;
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
@@ -1066,7 +1102,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     // wave still reaches every barrier.
     asm volatile("s_mov_b64 exec, %0" ::"s"(item.mask) : "memory");
     constexpr bool active = true;
-    ImgPtr img = to_const(a.img + item.image);
+    ImgPtr img = to_const(a.img + item.image);                                   // Q28: the workgroup's image (scalar loads)
+    const DevImage *img_l = a.img + (FLAVOR ? a.stream_image[stream] : 0u);      // float: this lane's own image (vector loads)
 
     uint32_t *gs = a.state + (size_t)wg * sm.n_slots * ROW + col;
     for (int s = wave; s < sm.lds_slots; s += 4) lds[s * kLanes + lane] = gs[(size_t)s * ROW];
@@ -1076,7 +1113,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     g.n_blocks = a.n_blocks; g.B = a.block_len;
     g.cpb = (g.B + T - 1) / T;
     g.items = g.n_blocks * g.cpb;
-    g.lag = (img->flags & IF_LEVELLER_ON) ? g.cpb : 0u;
+    // float (per-lane images): the schedule cannot depend on one lane's flags, every lane goes through the ring
+    g.lag = FLAVOR ? g.cpb : ((img->flags & IF_LEVELLER_ON) ? g.cpb : 0u);
     g.steps = g.items + g.lag + 1;
 
     if (wave == 0 && FLAVOR == 0) {
@@ -1151,7 +1189,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             const bool do_item = st >= g.lag && st < g.items + g.lag;
             const uint32_t q = st - g.lag;
             if (do_p1 || do_item) {
-                master_step_f32<TAIL>(a, img, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
+                master_step_f32<TAIL>(a, img_l, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
             }
             if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
             if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
@@ -1185,7 +1223,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
-                output_item_f32<TAIL>(a, img, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
+                output_item_f32<TAIL>(a, img_l, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
             WT_BEFORE_BARRIER;

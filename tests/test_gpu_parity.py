@@ -171,6 +171,43 @@ def test_many_presets_one_process_call(flavor):
     d.close()
 
 
+def test_every_stream_its_own_preset():
+    """every float stream carries a different preset — different band kinds at the same band index (SVF
+    forms vs biquad, bypassed), leveller / crossfeed / loudness on or off, muted and disabled outputs, delays from 0 to
+    the alias value, different preamps.  The one-stream float kernel reads per-lane parameter images, so this is two
+    launches, not one per preset; every stream must still match its own oracle, across two calls."""
+    fs, B, blocks, S = 48000, 48, 8, 200
+    d = Dspi(1, S, device=0); o = [Oracle(1, detmath=True) for _ in range(S)]
+    blob = WL.full_chain_blob(1)
+    for x in [d] + o:
+        x.set_rate(fs); x.set_volume(-9 * 256); x.load_bulk(blob)
+    R = W.REQ
+    f = lambda v: struct.pack("<f", v)
+    rng = np.random.default_rng(11)
+    types = [W.FILTER_PEAKING, W.FILTER_LOWSHELF, W.FILTER_HIGHSHELF, W.FILTER_LOWPASS, W.FILTER_HIGHPASS, W.FILTER_FLAT]
+    for s_ in range(S):
+        reqs = [(R["SET_PREAMP"], 0, f(-15.0 + 0.1 * s_))]
+        ch, band = int(rng.integers(0, 11)), int(rng.integers(0, 10))
+        freq = float(rng.choice([60.0, 400.0, 3000.0, 9000.0, 15000.0]))          # < 6.4 kHz: SVF, above: biquad (48 kHz)
+        reqs.append((R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, band, types[s_ % len(types)], 0, freq, 0.9, float(rng.uniform(-6, 6)))))
+        if s_ % 3 == 0: reqs.append((R["SET_LEVELLER_ENABLE"], 0, b"\x00"))
+        if s_ % 4 == 1: reqs.append((R["SET_CROSSFEED"], 0, b"\x00"))
+        if s_ % 5 == 2: reqs.append((R["SET_OUTPUT_MUTE"], int(rng.integers(0, 9)), b"\x01"))
+        if s_ % 7 == 3: reqs.append((R["SET_OUTPUT_ENABLE"], int(rng.integers(2, 8)), b"\x00"))
+        reqs.append((R["SET_OUTPUT_DELAY"], int(rng.integers(0, 8)), f(float(rng.choice([0.0, 0.1, 0.3, 7.7, 85.0])))))
+        for req, wv, pl in reqs:
+            assert d.vendor_set(req, wv, pl, stream=s_) == o[s_].vendor_set(req, wv, pl)
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
+    for c in range(2):
+        chunk = np.ascontiguousarray(pcm[:, c * blocks * B:(c + 1) * blocks * B])
+        pairs, sub, peaks = d.process_host(chunk, blocks, B)
+        for s_ in range(S):
+            rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B)
+            assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (c, s_)
+            assert o[s_].status() == d.status(s_)
+    d.close()
+
+
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_tiled_output_layout(flavor):
     """DSPI_OUT_TILED ([tile][output][frame][R]) carries exactly the words of the stream-major layout: packed and
