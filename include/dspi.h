@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DSPI_ABI_VERSION 1
+#define DSPI_ABI_VERSION 2   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
