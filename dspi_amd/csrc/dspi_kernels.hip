@@ -150,7 +150,7 @@ __device__ __forceinline__ void run_bands16(float (&x)[T], BandPtr bands, float 
 
 template <bool TAIL, int NB, bool SHELF_ONLY = false>
 __device__ __forceinline__ void run_bands(float (&x)[T], int n, BandPtr bands, float *__restrict__ st) {
-    if (TAIL) run_bands_f32<true, NB, SHELF_ONLY>(x, n, bands, st);
+    if (TAIL && n != T) run_bands_f32<true, NB, SHELF_ONLY>(x, n, bands, st);
     else run_bands16<NB, SHELF_ONLY>(x, bands, st);
 }
 

@@ -209,6 +209,39 @@ def emit(name, kinds, out, packed):
     out.append("")
 
 
+def emit_tail(name, kinds, out):
+    """Packed, ragged chunk: same dispatch, samples in program order with a scalar early exit in front of each one
+    (n is wave-uniform: the last chunk of a 44/45-frame packet).  Keeps x[] in registers where the C++ twin with its
+    guarded loops lets the compiler demote the arrays to scratch."""
+    def blk(kind):
+        lines = []
+        for i in range(T):
+            lines += ["s_cmp_le_u32 %%[n], %d" % i, "s_cbranch_scc1 .Lend_%="]
+            lines += [pk_line(op, d, a, b, i) for (op, d, a, b) in ops(kind)]
+        return lines
+    lines = ["s_cmp_eq_u32 %[k], 0", "s_cbranch_scc1 .Lend_%="]
+    for kname, kval in kinds[:-1]:
+        lines += ["s_cmp_eq_u32 %%[k], %d" % kval, "s_cbranch_scc1 .L%s_%%=" % kname]
+    lines += blk(kinds[-1][0]) + ["s_branch .Lend_%="]
+    for kname, kval in kinds[:-1]:
+        lines += [".L%s_%%=:" % kname] + blk(kname) + ["s_branch .Lend_%="]
+    lines += [".Lend_%=:"]
+    body = '\n'.join('        "%s\\n\\t"' % l for l in lines)
+    xs = ', '.join('[x%d] "+v"(x[%d])' % (i, i) for i in range(T))
+    tn = ['t%d_%d' % (s_, j) for s_ in range(NTSETS) for j in range(4)]
+    ts = ', '.join('[%s] "=&v"(%s)' % (t, t) for t in tn)
+    out.append("__device__ __forceinline__ void %s(v2f (&x)[16], v2f &s1, v2f &s2, uint32_t kind, v2f c01, v2f c23, v2f c45, uint32_t n) {" % name)
+    out.append("    v2f %s;" % ', '.join(tn))
+    out.append("    const v2f two = {2.0f, 2.0f};")
+    out.append("    asm volatile(")
+    out.append(body)
+    out.append("        : %s, [s1] \"+v\"(s1), [s2] \"+v\"(s2), %s" % (xs, ts))
+    out.append("        : [k] \"s\"(kind), [c01] \"s\"(c01), [c23] \"s\"(c23), [c45] \"s\"(c45), [two] \"s\"(two), [n] \"s\"(n)")
+    out.append("        : \"scc\");")
+    out.append("}")
+    out.append("")
+
+
 HEADER = ["// %s — GENERATED by tools/gen_bandloops.py; do not edit by hand.",
           "// Hand-scheduled gfx950 band loops: 16 samples of one EQ band, in place on tied VGPRs (\"+v\"), coefficients in SGPRs.",
           "// One multiply/add/subtract per reference operation, in the reference's association order (dsp_pipeline.c:298-362).",
@@ -224,6 +257,9 @@ def main():
         pre = "band16pk" if packed else "band16"
         emit(pre + "_any", allk, out, packed)
         emit(pre + "_shelf", [('SH', 5)], out, packed)      # loudness stages are shelves (or bypassed)
+        if packed:
+            emit_tail("band16pk_any_tail", allk, out)
+            emit_tail("band16pk_shelf_tail", [('SH', 5)], out)
         path = os.path.join(here, fname)
         open(path, "w").write('\n'.join(out))
         print("wrote", os.path.normpath(path))
