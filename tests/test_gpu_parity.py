@@ -171,12 +171,13 @@ def test_many_presets_one_process_call(flavor):
     d.close()
 
 
-def test_every_stream_its_own_preset():
+@pytest.mark.parametrize("fs,B,depth,S", [(48000, 48, 16, 200), (44100, 45, 24, 70)])
+def test_every_stream_its_own_preset(fs, B, depth, S):
     """every float stream carries a different preset — different band kinds at the same band index (SVF
     forms vs biquad, bypassed), leveller / crossfeed / loudness on or off, muted and disabled outputs, delays from 0 to
     the alias value, different preamps.  The one-stream float kernel reads per-lane parameter images, so this is two
     launches, not one per preset; every stream must still match its own oracle, across two calls."""
-    fs, B, blocks, S = 48000, 48, 8, 200
+    blocks = 8
     d = Dspi(1, S, device=0); o = [Oracle(1, detmath=True) for _ in range(S)]
     blob = WL.full_chain_blob(1)
     for x in [d] + o:
@@ -200,9 +201,10 @@ def test_every_stream_its_own_preset():
     pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
     for c in range(2):
         chunk = np.ascontiguousarray(pcm[:, c * blocks * B:(c + 1) * blocks * B])
-        pairs, sub, peaks = d.process_host(chunk, blocks, B)
+        data = chunk if depth == 16 else WL.pcm16_to_pcm24_bytes(chunk)
+        pairs, sub, peaks = d.process_host(data, blocks, B, depth)
         for s_ in range(S):
-            rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B)
+            rp, rs, rk, _ = o[s_].process(data[s_], blocks, B, depth)
             assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (c, s_)
             assert o[s_].status() == d.status(s_)
     d.close()
