@@ -363,6 +363,22 @@ int dspi_load_preset_slot(dspi_ctx *c, int32_t stream, const void *image, size_t
     if (!image) return DSPI_E_INVAL;
     return for_targets(c, stream, [&](Params &p) { return p.load_slot(image, len, expect_slot); });
 }
+int dspi_load_flash_dump(dspi_ctx *c, int32_t stream, const void *dump, size_t len) {
+    if (!dump) return DSPI_E_INVAL;
+    if (len < kFlashDumpBytes) return DSPI_E_SHORT;
+    return for_targets(c, stream, [&](Params &p) { return p.load_flash_dump(dump, len); });
+}
+int dspi_flash_read_directory(const void *dump, size_t len, dspi_flash_dir *out) {
+    if (!dump || !out) return DSPI_E_INVAL;
+    FlashDirectory d;
+    parse_flash_directory(dump, len, d);
+    memset(out, 0, sizeof *out);
+    out->valid = d.valid; out->version = d.version;
+    out->startup_mode = d.startup_mode; out->default_slot = d.default_slot; out->last_active_slot = d.last_active_slot; out->include_pins = d.include_pins;
+    out->slot_occupied = d.slot_occupied; out->master_volume_mode = d.master_volume_mode; out->master_volume_db = d.master_volume_db;
+    memcpy(out->slot_names, d.slot_names, sizeof out->slot_names);
+    return DSPI_OK;
+}
 int dspi_save_preset_slot(dspi_ctx *c, int32_t stream, void *image, size_t cap, int slot_index) {
     if (!c || !image || !valid_stream(c, stream)) return DSPI_E_INVAL;
     return readable(c, stream).save_slot(image, cap, slot_index);

@@ -8,6 +8,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <vector>
 #include <xmmintrin.h>
 
 namespace dspi {
@@ -828,6 +829,79 @@ int Params::load_slot(const void *image, size_t len, int expect_slot) {
     transition_core1();
     service();
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// flash dump: directory sector, startup-slot selection, legacy migration (flash_storage.c:370-417, :997-1105)
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t kDirMagic = 0x44535032u, kLegacyMagic = 0x44535031u;     // "DSP2", "DSP1" (flash_storage.c:64-68)
+constexpr size_t kSector = 4096;
+template <class V> V rd_at(const uint8_t *p, size_t off) { V v; memcpy(&v, p + off, sizeof v); return v; }
+}
+
+bool parse_flash_directory(const void *dump, size_t len, FlashDirectory &d) {
+    memset(&d, 0, sizeof d);
+    if (!dump || len < kSector) return false;
+    const uint8_t *p = static_cast<const uint8_t *>(dump);
+    if (rd_at<uint32_t>(p, 0) != kDirMagic) return false;
+    const uint16_t version = rd_at<uint16_t>(p, 4);
+    const uint32_t crc = rd_at<uint32_t>(p, 8);
+    // v2: header 12, startup 4, occupied 2, mode 1, pad 1, master dB 4, names 320 = 344; v1 has no master dB = 340
+    const size_t total = version == 2 ? 344 : version == 1 ? 340 : 0;
+    if (!total || crc32_edb88320(p + 12, total - 12) != crc) return false;
+    d.valid = 1; d.version = version;
+    d.startup_mode = p[12]; d.default_slot = p[13]; d.last_active_slot = p[14]; d.include_pins = p[15];
+    d.slot_occupied = rd_at<uint16_t>(p, 16);
+    if (version == 2) {
+        d.master_volume_mode = p[18];
+        d.master_volume_db = rd_at<float>(p, 20);
+        memcpy(d.slot_names, p + 24, sizeof d.slot_names);
+    } else {                      // v1 -> v2 in memory (flash_storage.c:391-411)
+        d.master_volume_mode = p[18] ? 1 : 0;
+        d.master_volume_db = kMasterDefaultDb;
+        memcpy(d.slot_names, p + 20, sizeof d.slot_names);
+    }
+    return true;
+}
+
+// Return: 0..9 slot loaded | 16+slot: that slot was selected but is empty or corrupt -> factory defaults |
+//         32: no directory, legacy sector migrated into slot 0 and loaded | 48: nothing usable -> factory defaults | -4 short dump
+// The SELECTION is preset_boot_load's (flash_storage.c:1047-1105); the APPLICATION is preset_load's (:794-849: mute,
+// delay lines zeroed), because a context is a running device, not one that is booting.
+int Params::load_flash_dump(const void *dump, size_t len) {
+    if (!dump || len < kFlashDumpBytes) return -4;
+    const uint8_t *p = static_cast<const uint8_t *>(dump);
+    FlashDirectory d;
+    if (parse_flash_directory(dump, len, d)) {
+        uint8_t target = d.startup_mode == 1 ? d.last_active_slot : d.default_slot;      // PRESET_STARTUP_LAST_ACTIVE
+        if (target >= 10) { target = d.default_slot; if (target >= 10) target = 0; }
+        dir_master_volume_mode = d.master_volume_mode; dir_master_volume_db = d.master_volume_db; dir_include_pins = d.include_pins;
+        if ((d.slot_occupied >> target) & 1u)
+            if (load_slot(p + (1 + (size_t)target) * kSector, (size_t)slot_size(), target) == 0) return target;
+        factory_reset();
+        return 16 + target;
+    }
+    // no directory: migrate_legacy (flash_storage.c:997-1045) — the legacy sector's data section has the slot's layout
+    const uint8_t *lg = p + 11 * kSector;
+    const size_t legacy_bytes = 12 + (size_t)n_ch * kStoredBands * 16 + 4 + 4 + (size_t)n_ch * 4 + 12 + 4 + 4 + 8 + 4 + 8 +
+                                (size_t)2 * n_out * 8 + (size_t)n_out * 12 + 8;
+    dir_master_volume_mode = 0; dir_master_volume_db = kMasterDefaultDb;
+    if (rd_at<uint32_t>(lg, 0) == kLegacyMagic && crc32_edb88320(lg + 12, legacy_bytes - 12) == rd_at<uint32_t>(lg, 8)) {
+        std::vector<uint8_t> slot((size_t)slot_size(), 0);
+        const uint32_t magic = kSlotMagic; const uint16_t version = rd_at<uint16_t>(lg, 4), idx = 0;
+        memcpy(&slot[0], &magic, 4); memcpy(&slot[4], &version, 2); memcpy(&slot[6], &idx, 2);
+        memcpy(&slot[12], lg + 12, legacy_bytes - 12);
+        const uint32_t crc = crc32_edb88320(&slot[12], (size_t)slot_size() - 12);
+        memcpy(&slot[8], &crc, 4);
+        dir_include_pins = 0;                       // "Legacy migration: don't override pins" (:1091)
+        const int rc = load_slot(slot.data(), slot.size(), 0);
+        dir_include_pins = 1;
+        if (rc == 0) return 32;
+    }
+    dir_include_pins = 1;                           // dir_ensure (:440-457)
+    factory_reset();
+    return 48;
 }
 
 int Params::save_slot(void *image, size_t cap, int slot_index) const {   // collect_live_state, flash_storage.c:464-552

@@ -24,6 +24,19 @@ static_assert(sizeof(Recipe) == 16, "EqParamPacket is 16 bytes");
 
 enum FilterType : uint8_t { FT_FLAT = 0, FT_PEAKING, FT_LOWSHELF, FT_HIGHSHELF, FT_LOWPASS, FT_HIGHPASS };
 
+// the preset directory sector of a flash dump (flash_storage.c:95-131), version 1 or 2, after CRC validation
+struct FlashDirectory {
+    int valid;                 // 0: no / corrupt / unknown-version directory
+    int version;
+    uint8_t startup_mode, default_slot, last_active_slot, include_pins;
+    uint16_t slot_occupied;
+    uint8_t master_volume_mode;
+    float master_volume_db;
+    char slot_names[10][32];
+};
+constexpr size_t kFlashDumpBytes = 12 * 4096;      // directory + 10 slots + legacy sector (flash_storage.c:4-15)
+bool parse_flash_directory(const void *dump, size_t len, FlashDirectory &out);
+
 struct BandCoeffs {          // derived; the coefficient half of the reference's Biquad (config.h:417-438)
     Word b0, b1, b2, a1, a2; // float flavour: .f ; Q28 flavour: .i
     float sva1, sva2, sva3, svm0, svm1, svm2;
@@ -47,6 +60,7 @@ public:
     int collect_bulk(void *blob, size_t cap) const;
     int load_slot(const void *image, size_t len, int expect_slot);
     int save_slot(void *image, size_t cap, int slot_index) const;
+    int load_flash_dump(const void *dump, size_t len);      // preset_boot_load's selection on a 48 KB flash image
     int vendor_set(uint8_t req, uint16_t wValue, const void *payload, uint16_t len);
     int vendor_get(uint8_t req, uint16_t wValue, void *buf, uint16_t cap, const uint16_t *peaks, uint16_t *clip_flags);
     void set_volume(int16_t v);

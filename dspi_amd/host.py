@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
     L.dspi_load_bulk.argtypes = [vp, i32, vp, C.c_size_t]
     L.dspi_collect_bulk.argtypes = [vp, i32, vp, C.c_size_t]
     L.dspi_load_preset_slot.argtypes = [vp, i32, vp, C.c_size_t, C.c_int]
+    L.dspi_load_flash_dump.argtypes = [vp, i32, vp, C.c_size_t]
+    L.dspi_flash_read_directory.argtypes = [vp, C.c_size_t, vp]
     L.dspi_save_preset_slot.argtypes = [vp, i32, vp, C.c_size_t, C.c_int]
     L.dspi_vendor_set.argtypes = [vp, i32, u8, u16, vp, u16]
     L.dspi_vendor_get.argtypes = [vp, i32, u8, u16, vp, u16]
@@ -121,6 +123,10 @@ class Dspi:
 
     def load_slot(self, image: bytes, expect_slot: int = -1, stream: int = ALL) -> int:
         return self.L.dspi_load_preset_slot(self.h, stream, image, len(image), expect_slot)
+
+    def load_flash_dump(self, dump: bytes, stream: int = ALL) -> int:
+        """dspi_load_flash_dump: 0..9 slot loaded | 16+n selected slot empty/corrupt | 32 legacy migrated | 48 factory."""
+        return self.L.dspi_load_flash_dump(self.h, stream, dump, len(dump))
 
     def save_slot(self, slot_index: int = 0, stream: int = 0) -> bytes:
         buf = C.create_string_buffer(4096)

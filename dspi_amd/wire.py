@@ -168,3 +168,43 @@ def new_bulk(flavor: int) -> np.ndarray:
 def set_band(b: np.ndarray, ch: int, band: int, ftype: int, freq: float, q: float, gain_db: float) -> None:
     e = b["eq"][ch, band]
     e["type"], e["freq"], e["q"], e["gain_db"] = ftype, freq, q, gain_db
+
+
+# --- flash dump (flash_storage.c:4-26, :95-131): 12 sectors of 4 KB — directory, 10 preset slots, legacy sector -------
+FLASH_SECTOR = 4096
+FLASH_DUMP_BYTES = 12 * FLASH_SECTOR
+DIR_MAGIC, LEGACY_MAGIC = 0x44535032, 0x44535031
+
+
+def flash_directory(version=2, startup_mode=0, default_slot=0, last_active_slot=0, include_pins=1, slot_occupied=0,
+                    master_volume_mode=0, master_volume_db=-20.0, names=None) -> bytes:
+    """One directory sector image (PresetDirectory v2, or PresetDirectory_v1 where master_volume_mode is the old
+    include_master_volume flag), CRC filled in."""
+    import struct
+    names = names or {}
+    body = struct.pack("<BBBBHBB", startup_mode, default_slot, last_active_slot, include_pins, slot_occupied, master_volume_mode, 0)
+    if version == 2:
+        body += struct.pack("<f", master_volume_db)
+    for n in range(10):
+        body += names.get(n, "").encode()[:31].ljust(32, b"\0")
+    hdr = struct.pack("<IHHI", DIR_MAGIC, version, 0, zlib.crc32(body) & 0xFFFFFFFF)
+    return (hdr + body).ljust(FLASH_SECTOR, b"\xff")
+
+
+def flash_dump(directory: bytes = None, slots=None, legacy: bytes = None) -> bytes:
+    """Assemble a 48 KB dump: erased flash (0xFF) except the given directory sector, slot images {n: bytes}, legacy sector."""
+    img = bytearray(b"\xff" * FLASH_DUMP_BYTES)
+    if directory: img[0:len(directory)] = directory
+    for n, s in (slots or {}).items():
+        img[(1 + n) * FLASH_SECTOR:(1 + n) * FLASH_SECTOR + len(s)] = s
+    if legacy: img[11 * FLASH_SECTOR:11 * FLASH_SECTOR + len(legacy)] = legacy
+    return bytes(img)
+
+
+def legacy_sector_from_slot(slot_image: bytes, flavor: int, version: int = 7) -> bytes:
+    """A LegacyFlashStorage image (flash_storage.c:203-232) carrying the data section of a slot image up to the pins."""
+    import struct
+    n_ch, n_out = (11, 9) if flavor else (7, 5)
+    legacy_bytes = 12 + n_ch * 12 * 16 + 4 + 4 + n_ch * 4 + 12 + 4 + 4 + 8 + 4 + 8 + 2 * n_out * 8 + n_out * 12 + 8
+    data = slot_image[12:legacy_bytes]
+    return struct.pack("<IHHI", LEGACY_MAGIC, version, 0, zlib.crc32(data) & 0xFFFFFFFF) + data

@@ -111,6 +111,28 @@ int dspi_load_preset_slot(dspi_ctx *ctx, int32_t stream, const void *image, size
 /* collect_live_state: flash_storage.c:464-552.  Returns the image size (2864 / 1840). */
 int dspi_save_preset_slot(dspi_ctx *ctx, int32_t stream, void *image, size_t cap, int slot_index);
 
+/* ---- flash dump --------------------------------------------------------------- */
+/* A raw image of the firmware's 48 KB preset area (flash_storage.c:4-26): sector 0 = preset directory (v1 or v2),
+ * sectors 1-10 = preset slots 0-9, sector 11 = the legacy single-preset sector. */
+#define DSPI_FLASH_DUMP_BYTES (12 * 4096)
+typedef struct dspi_flash_dir {
+    int32_t valid;                 /* 0: no directory, bad CRC or unknown version */
+    int32_t version;               /* 1 or 2 as stored; v1 fields are mapped to v2 as the firmware's migration does (:391-411) */
+    uint8_t startup_mode;          /* 0 PRESET_STARTUP_SPECIFIED, 1 _LAST_ACTIVE (config.h:258-259) */
+    uint8_t default_slot, last_active_slot, include_pins;
+    uint16_t slot_occupied;        /* bit n: slot n holds a preset */
+    uint8_t master_volume_mode, pad_;
+    float master_volume_db;
+    char slot_names[10][32];
+} dspi_flash_dir;
+/* dir_load_cache: flash_storage.c:370-417 (no context needed) */
+int dspi_flash_read_directory(const void *dump, size_t len, dspi_flash_dir *out);
+/* Picks the startup preset the way preset_boot_load does (flash_storage.c:1047-1105: startup mode, occupancy, slot
+ * validation, legacy-sector migration :997-1045) and applies it the way REQ_PRESET_LOAD does (a context is a running
+ * device).  Returns 0..9 = that slot was loaded; 16+n = slot n was selected but is empty or corrupt, factory defaults
+ * applied; 32 = no directory, legacy sector migrated and loaded; 48 = nothing usable, factory defaults; negative DSPI_E_*. */
+int dspi_load_flash_dump(dspi_ctx *ctx, int32_t stream, const void *dump, size_t len);
+
 /* ---- incremental parameters ------------------------------------------------------------ */
 /* vendor_cmd_packet (usb_audio.c:1632-2021): payloads shorter than the request needs are ignored, as upstream */
 int dspi_vendor_set(dspi_ctx *ctx, int32_t stream, uint8_t bRequest, uint16_t wValue, const void *payload, uint16_t len);

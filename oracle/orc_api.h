@@ -33,6 +33,7 @@ int orc_load_bulk(orc_ctx *, const void *blob, uint32_t len);     /* 0 or -1..-4
 int orc_collect_bulk(orc_ctx *, void *blob2896);
 int orc_load_preset_slot(orc_ctx *, const void *image, uint32_t len, int expect_slot /* -1: any */);  /* PRESET_OK / PRESET_ERR_CRC */
 int orc_save_preset_slot(orc_ctx *, void *image, int slot_index);
+int orc_load_flash_dump(orc_ctx *, const void *dump48k, uint32_t len);   /* 0..9 | 16+n | 32 | 48 | -4, see orc_chain.c */
 int orc_vendor_set(orc_ctx *, uint8_t bRequest, uint16_t wValue, const void *payload, uint16_t len);  /* 0, -1 unsupported */
 int orc_vendor_get(orc_ctx *, uint8_t bRequest, uint16_t wValue, void *buf, uint16_t cap);            /* bytes, -1 unsupported/stall */
 void orc_get_status(orc_ctx *, void *buf);  /* REQ_GET_STATUS wValue 9 layout: 26 B float flavour, 18 B Q28 */

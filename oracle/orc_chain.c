@@ -1153,6 +1153,78 @@ int orc_load_preset_slot(orc_ctx *c, const void *image, uint32_t len, int expect
     return rc;
 }
 
+/* ---- flash dump: directory, startup-slot selection, legacy migration ----
+ * flash_storage.c:95-131 (directory v1 / v2), :370-417 (dir_load_cache), :997-1045 (migrate_legacy), :1047-1105
+ * (preset_boot_load).  flash_storage.c needs pico-sdk (hardware/flash.h): restated, PARITY UNPINNED; the slot payloads
+ * go through orc_load_preset_slot, i.e. the selection is the boot path's and the application is preset_load's. */
+typedef struct __attribute__((packed)) {
+    uint32_t magic; uint16_t version; uint16_t reserved; uint32_t crc32;
+    uint8_t startup_mode, default_slot, last_active_slot, include_pins;
+    uint16_t slot_occupied; uint8_t include_master_volume; uint8_t padding[1];
+    char slot_names[PRESET_SLOTS][PRESET_NAME_LEN];
+} OrcDirV1;
+typedef struct __attribute__((packed)) {
+    uint32_t magic; uint16_t version; uint16_t reserved; uint32_t crc32;
+    uint8_t startup_mode, default_slot, last_active_slot, include_pins;
+    uint16_t slot_occupied; uint8_t master_volume_mode; uint8_t padding[1];
+    float master_volume_db;
+    char slot_names[PRESET_SLOTS][PRESET_NAME_LEN];
+} OrcDirV2;
+#define ORC_DIR_MAGIC 0x44535032u
+#define ORC_LEGACY_MAGIC 0x44535031u
+#define ORC_SECTOR 4096u
+#ifndef PRESET_STARTUP_LAST_ACTIVE
+#define PRESET_STARTUP_LAST_ACTIVE 1   /* config.h:259 */
+#endif
+
+int orc_load_flash_dump(orc_ctx *c, const void *dump, uint32_t len) {
+    if (len < 12u * ORC_SECTOR) return -4;
+    const uint8_t *p = (const uint8_t *)dump;
+    OrcDirV2 d2; memcpy(&d2, p, sizeof d2);
+    int have_dir = 0;
+    if (d2.magic == ORC_DIR_MAGIC) {
+        if (d2.version == 2) {
+            have_dir = crc32_((const uint8_t *)&d2.startup_mode, sizeof d2 - offsetof(OrcDirV2, startup_mode)) == d2.crc32;
+        } else if (d2.version == 1) {
+            OrcDirV1 d1; memcpy(&d1, p, sizeof d1);
+            if (crc32_((const uint8_t *)&d1.startup_mode, sizeof d1 - offsetof(OrcDirV1, startup_mode)) == d1.crc32) {
+                have_dir = 1;
+                d2.startup_mode = d1.startup_mode; d2.default_slot = d1.default_slot; d2.last_active_slot = d1.last_active_slot;
+                d2.include_pins = d1.include_pins; d2.slot_occupied = d1.slot_occupied;
+                d2.master_volume_mode = d1.include_master_volume ? MASTER_VOLUME_MODE_WITH_PRESET : MASTER_VOLUME_MODE_INDEPENDENT;
+                d2.master_volume_db = MASTER_VOL_DEFAULT_DB;
+            }
+        }
+    }
+    if (have_dir) {
+        uint8_t target = d2.startup_mode == PRESET_STARTUP_LAST_ACTIVE ? d2.last_active_slot : d2.default_slot;
+        if (target >= PRESET_SLOTS) { target = d2.default_slot; if (target >= PRESET_SLOTS) target = 0; }
+        c->dir_master_volume_mode = d2.master_volume_mode; c->dir_master_volume_db = d2.master_volume_db; c->dir_include_pins = d2.include_pins;
+        if (d2.slot_occupied & (1u << target))
+            if (orc_load_preset_slot(c, p + (1u + target) * ORC_SECTOR, sizeof(OrcPresetSlot), target) == PRESET_OK) return target;
+        orc_factory_defaults(c);
+        return 16 + target;
+    }
+    const uint8_t *lg = p + 11u * ORC_SECTOR;
+    const size_t legacy_bytes = offsetof(OrcPresetSlot, channel_names);       /* LegacyFlashStorage ends where the names begin */
+    uint32_t magic, crc; uint16_t version;
+    memcpy(&magic, lg, 4); memcpy(&version, lg + 4, 2); memcpy(&crc, lg + 8, 4);
+    c->dir_master_volume_mode = MASTER_VOLUME_MODE_INDEPENDENT; c->dir_master_volume_db = MASTER_VOL_DEFAULT_DB;
+    if (magic == ORC_LEGACY_MAGIC && crc32_(lg + 12, legacy_bytes - 12) == crc) {
+        OrcPresetSlot s; memset(&s, 0, sizeof s);
+        memcpy((uint8_t *)&s + 12, lg + 12, legacy_bytes - 12);
+        s.magic = SLOT_MAGIC; s.version = version; s.slot_index = 0;
+        s.crc32 = crc32_((const uint8_t *)&s.filter_recipes, sizeof(OrcPresetSlot) - offsetof(OrcPresetSlot, filter_recipes));
+        c->dir_include_pins = 0;
+        int rc = orc_load_preset_slot(c, &s, sizeof s, 0);
+        c->dir_include_pins = 1;
+        if (rc == PRESET_OK) return 32;
+    }
+    c->dir_include_pins = 1;
+    orc_factory_defaults(c);
+    return 48;
+}
+
 int orc_save_preset_slot(orc_ctx *c, void *image, int slot_index) {
     collect_live_state(c, (OrcPresetSlot *)image, (uint8_t)slot_index);
     return (int)sizeof(OrcPresetSlot);

@@ -52,6 +52,7 @@ def load(flavor: int, ref: bool = False) -> C.CDLL:
     lib.orc_collect_bulk.argtypes = [C.c_void_p, C.c_void_p]
     lib.orc_load_preset_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
     lib.orc_save_preset_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    if hasattr(lib, "orc_load_flash_dump"): lib.orc_load_flash_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.orc_vendor_set.argtypes = [C.c_void_p, C.c_uint8, C.c_uint16, C.c_void_p, C.c_uint16]
     lib.orc_vendor_get.argtypes = [C.c_void_p, C.c_uint8, C.c_uint16, C.c_void_p, C.c_uint16]
     lib.orc_get_status.argtypes = [C.c_void_p, C.c_void_p]
@@ -116,6 +117,9 @@ class Oracle:
 
     def load_slot(self, image: bytes, expect_slot: int = -1) -> int:
         return self.lib.orc_load_preset_slot(self.h, image, len(image), expect_slot)
+
+    def load_flash_dump(self, dump: bytes) -> int:
+        return self.lib.orc_load_flash_dump(self.h, dump, len(dump))
 
     def save_slot(self, slot_index: int = 0) -> bytes:
         n = self.lib.orc_preset_slot_size()
