@@ -135,9 +135,13 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL ("nccl") over xGMI; DSPI_BENCH_BACKEND=gloo exists only to smoke-test the multi-rank control flow on a
+        # box with fewer GPUs than ranks (ranks then share devices)
+        backend = os.environ.get("DSPI_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernel is the only audio path")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -188,7 +192,7 @@ def main():
     kernel_ms = ev.elapsed_ms(e0, e1) / args.steps     # one chain-kernel launch per step
     elapsed = t1 - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the only collective: 8 bytes over RCCL/xGMI
         elapsed = float(t.item())
 
