@@ -27,10 +27,10 @@ __global__ void bands(float* out, uint32_t kind, v2f c01, v2f c23, v2f c45, int 
 
 int main() {
     float* dout; CK(hipMalloc(&dout, 1 << 24));
-    const int per_sample[6] = {0, 9, 12, 15, 14, 17};
+    const int per_sample[6] = {0, 9, 10, 13, 12, 15};   // with the SVF state update as one v_pk_fma_f32
     const char* names[6] = {"", "biquad", "svf-lp", "svf-hp", "svf-pk", "svf-shelf"};
     const int reps = 2000;
-    for (int wps : {1, 2})
+    for (int wps : {1, 2, 3})
         for (uint32_t kind = 1; kind <= 5; kind++) {
             dim3 grid(256 * wps), block(256);
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
