@@ -159,22 +159,36 @@ __device__ __forceinline__ void run_bands(float (&x)[T], int n, BandPtr bands, f
 // run together, kinds one after the other).  Same arithmetic, same order.
 template <bool TAIL, int NB, bool SHELF_ONLY = false>
 __device__ __forceinline__ void run_bands(float (&x)[T], int n, const DevBand *bands, float *__restrict__ st) {
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    // band b+1's 32-byte descriptor (two 16-byte vector loads per lane) and state pair are requested before band b runs
+    u32x8 cur = *reinterpret_cast<const u32x8 *>(bands);
+    float s1 = st[0], s2 = st[kLanes];
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
-        const uint32_t kind = bands[b].kind;
-        if (kind == K_BYPASS) continue;
-        const float c0 = bands[b].c[0].f, c1 = bands[b].c[1].f, c2 = bands[b].c[2].f, c3 = bands[b].c[3].f, c4 = bands[b].c[4].f, c5 = bands[b].c[5].f;
-        float s1 = st[b * 2 * kLanes], s2 = st[b * 2 * kLanes + kLanes];
-        if (SHELF_ONLY) band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5);
-        else switch (kind) {
-            case K_BIQUAD: band_loop_f32<TAIL, K_BIQUAD>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-            case K_SVF_LP: band_loop_f32<TAIL, K_SVF_LP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-            case K_SVF_HP: band_loop_f32<TAIL, K_SVF_HP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-            case K_SVF_PK: band_loop_f32<TAIL, K_SVF_PK>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-            default: band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+        const int bn = (b + 1 < NB) ? b + 1 : b;
+        const u32x8 nxt = *reinterpret_cast<const u32x8 *>(bands + bn);
+        const float ns1 = st[bn * 2 * kLanes], ns2 = st[bn * 2 * kLanes + kLanes];
+        const uint32_t kind = cur[6];
+        const uint32_t k0 = __builtin_amdgcn_readfirstlane(kind);
+        const float c0 = as_f(cur[0]), c1 = as_f(cur[1]), c2 = as_f(cur[2]), c3 = as_f(cur[3]), c4 = as_f(cur[4]), c5 = as_f(cur[5]);
+        if ((!TAIL || n == T) && __all(kind == k0)) {
+            // the usual case: all lanes of the wave use the same form at this band index (presets of one product family):
+            // the hand-written loop, with per-lane coefficients in VGPRs
+            if (SHELF_ONLY) band16v_shelf(x, s1, s2, k0, c0, c1, c2, c3, c4, c5);
+            else band16v_any(x, s1, s2, k0, c0, c1, c2, c3, c4, c5);
+        } else if (kind != K_BYPASS) {
+            if (SHELF_ONLY) band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5);
+            else switch (kind) {
+                case K_BIQUAD: band_loop_f32<TAIL, K_BIQUAD>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_LP: band_loop_f32<TAIL, K_SVF_LP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_HP: band_loop_f32<TAIL, K_SVF_HP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_PK: band_loop_f32<TAIL, K_SVF_PK>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                default: band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            }
         }
         st[b * 2 * kLanes] = s1;
         st[b * 2 * kLanes + kLanes] = s2;
+        cur = nxt; s1 = ns1; s2 = ns2;
     }
 }
 

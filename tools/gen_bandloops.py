@@ -172,7 +172,7 @@ def block_pk(kind):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def emit(name, kinds, out, packed):
+def emit(name, kinds, out, packed, vcoef=False):
     """One asm statement that dispatches on the (wave-uniform) band kind with scalar branches and runs the
     matching 16-sample loop.  Keeping the dispatch inside the asm means the compiler sees a single in-place
     update of x[0..15] — no phi copies on any path."""
@@ -197,7 +197,7 @@ def emit(name, kinds, out, packed):
         out.append("    const v2f two = {2.0f, 2.0f};")
     else:
         ts = ', '.join('[t%d] "=&v"(t%d)' % (i, i) for i in range(4))
-        cs = ', '.join('[c%d] "s"(c%d)' % (i, i) for i in range(6))
+        cs = ', '.join('[c%d] "%s"(c%d)' % (i, 'v' if vcoef else 's', i) for i in range(6))
         out.append("__device__ __forceinline__ void %s(float (&x)[16], float &s1, float &s2, uint32_t kind, float c0, float c1, float c2, float c3, float c4, float c5) {" % name)
         out.append("    float t0, t1, t2, t3;")
     out.append("    asm volatile(")
@@ -257,6 +257,9 @@ def main():
         pre = "band16pk" if packed else "band16"
         emit(pre + "_any", allk, out, packed)
         emit(pre + "_shelf", [('SH', 5)], out, packed)      # loudness stages are shelves (or bypassed)
+        if not packed:      # per-lane parameter kernel: coefficients are per-lane values (VGPRs), the kind is wave-uniform here
+            emit("band16v_any", allk, out, False, vcoef=True)
+            emit("band16v_shelf", [('SH', 5)], out, False, vcoef=True)
         if packed:
             emit_tail("band16pk_any_tail", allk, out)
             emit_tail("band16pk_shelf_tail", [('SH', 5)], out)
