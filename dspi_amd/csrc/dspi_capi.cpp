@@ -175,19 +175,31 @@ int rebuild_launch_lists(dspi_ctx *c) {
             auto &v = c->launch_items[lev][k];
             v.clear();
             if (k >= 2) {
-                if (lev == 0) {
-                    std::map<uint32_t, uint64_t> rows;
+                // float: lanes with one stream of an image (k = 2 first, 3 second stream); Q28 (k = 2): rows that hold
+                // several images.  Per-lane parameter kernel: all images of a row merge into one item.
+                if (lev == 0 && (c->flavor || k == 2)) {
+                    std::map<uint32_t, std::pair<uint64_t, int>> rows;      // row -> (lane mask, number of images)
+                    const int src = c->flavor ? k : 0;
                     for (size_t i = 0; i < c->images.size(); i++)
                         if (c->image_refs[i] > 0)
-                            for (const WgItem &it : c->image_items[k][i]) rows[it.wg] |= it.mask;
-                    for (const auto &r : rows) v.push_back(WgItem{r.first, 0u, r.second, 0ull});
+                            for (const WgItem &it : c->image_items[src][i]) { auto &r = rows[it.wg]; r.first |= it.mask; r.second++; }
+                    for (const auto &r : rows)
+                        if (c->flavor || r.second.second > 1) v.push_back(WgItem{r.first, 0u, r.second.first, 0ull});
                 }
             } else {
+                std::map<uint32_t, int> per_row;       // Q28: rows with one image keep the workgroup-uniform path
+                if (!c->flavor && k == 0)
+                    for (size_t i = 0; i < c->images.size(); i++)
+                        if (c->image_refs[i] > 0)
+                            for (const WgItem &it : c->image_items[0][i]) per_row[it.wg]++;
                 for (size_t i = 0; i < c->images.size(); i++) {
                     if (c->image_refs[i] == 0) continue;
                     const int ilev = (c->flavor && (c->image_flags[i] & IF_LEVELLER_ON)) ? 1 : 0;
                     if (ilev != lev) continue;
-                    for (WgItem it : c->image_items[k][i]) { it.image = (uint32_t)i; v.push_back(it); }
+                    for (WgItem it : c->image_items[k][i]) {
+                        if (!c->flavor && k == 0 && per_row[it.wg] > 1) continue;
+                        it.image = (uint32_t)i; v.push_back(it);
+                    }
                 }
             }
             c->launch_item_offset[lev][k] = (uint32_t)total;
@@ -552,14 +564,14 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     }
     a.img = c->d_images;
     a.stream_image = c->d_stream_image;
-    // float flavour: lanes with both streams on one image go to the packed kernel (list 1), lanes with one stream of an
-    // image to the one-stream kernel per component (lists 2, 3); Q28: the one-stream kernel over list 0.  One launch
-    // per (leveller on/off, list) covers every image.
+    // float flavour: lanes with both streams on one image go to the packed kernel (list 1), every other lane to the
+    // per-lane-parameter kernel, once per lane component (lists 2, 3).  Q28: rows with one image run workgroup-uniform
+    // (list 0), rows with several in per-lane-parameter mode (list 2).  A launch covers every image.
     struct Launch { int list; int packed; uint32_t comp; };
-    static const Launch kF32[] = {{1, 1, 0}, {2, 0, 0}, {3, 0, 1}};
-    static const Launch kQ28[] = {{0, 0, 0}};
+    static const Launch kF32[] = {{1, 1, 0}, {2, 2, 0}, {3, 2, 1}};
+    static const Launch kQ28[] = {{0, 0, 0}, {2, 2, 0}};
     const Launch *ls = c->flavor ? kF32 : kQ28;
-    const int nl = c->flavor ? 3 : 1;
+    const int nl = c->flavor ? 3 : 2;
     for (int lev = 0; lev < 2; lev++)
         for (int l = 0; l < nl; l++) {
             const auto &items = c->launch_items[lev][ls[l].list];

@@ -26,8 +26,9 @@ struct KArgs {
 };
 
 size_t chain_lds_bytes(int flavor, int packed);
-// packed != 0 (float flavour only): items list lanes whose two streams are both processed (v_pk kernel);
-// packed == 0: scalar kernel, one stream per lane (float: the stream args.comp of each listed lane)
+// packed: 1 = packed float kernel (items list lanes whose two streams share the item's image); 0 = one stream per lane
+// with the item's image for the whole workgroup (Q28); 2 = one stream per lane, every lane its own image
+// (args.stream_image; float: the stream args.comp of each listed lane; Q28: rows with several presets)
 // leveller_on: IF_LEVELLER_ON of every image in args.items (the host groups them; the packed kernel is specialised on it)
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,

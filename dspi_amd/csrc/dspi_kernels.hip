@@ -750,6 +750,30 @@ __device__ __forceinline__ void run_bands_q28(int32_t (&x)[T], int n, BandPtr ba
     }
 }
 
+// per-lane parameters (a row whose streams carry different presets): coefficients by vector loads, the bypass flag per lane
+template <bool TAIL, int NB>
+__device__ __forceinline__ void run_bands_q28(int32_t (&x)[T], int n, const DevBand *bands, int32_t *__restrict__ st) {
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+        if (bands[b].kind == K_BYPASS) continue;
+        const int32_t b0 = bands[b].c[0].i, b1 = bands[b].c[1].i, b2 = bands[b].c[2].i, a1 = bands[b].c[3].i, a2 = bands[b].c[4].i;
+        int32_t s1 = st[b * 2 * kLanes], s2 = st[b * 2 * kLanes + kLanes];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (TAIL && i >= n) break;
+            const int32_t in = x[i];
+            const int32_t y = wadd(qmul(b0, in), s1);
+            const int32_t t1 = qmul(b1, in), t3 = qmul(b2, in);
+            const int32_t t2 = qmul(a1, y), t4 = qmul(a2, y);
+            s1 = wadd(wsub(t1, t2), s2);
+            s2 = wsub(t3, t4);
+            x[i] = y;
+        }
+        st[b * 2 * kLanes] = s1;
+        st[b * 2 * kLanes + kLanes] = s2;
+    }
+}
+
 struct MasterQ28 {
     int32_t lpL, lpR, apL, apR;
     int32_t env_l, env_r;
@@ -763,28 +787,31 @@ struct MasterQ28 {
     uint32_t clip;
 };
 
-template <bool TAIL>
-__device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g, MasterQ28 &m,
+// IMG = ImgPtr: the workgroup's image, scalar loads (PL false).  IMG = const DevImage *: per-lane images (PL true), for rows
+// whose streams carry different presets — then every lane's samples go through the ring (see master_step_f32).
+template <bool TAIL, bool PL, class IMG>
+__device__ __forceinline__ void master_step_q28(const KArgs &a, IMG img, const StateMap &sm, const Geo &g, MasterQ28 &m,
                                                 int32_t *__restrict__ lds_state, int32_t *__restrict__ xch_base, uint32_t wg, uint32_t lane, uint32_t stream,
                                                 bool do_p1, uint32_t k1, uint32_t c1, bool do_item, uint32_t kq, uint32_t cq, uint32_t q) {
     constexpr uint32_t ROW = make_state_map(0).row;
     const uint32_t col = lane;
     const uint32_t flags = img->flags;
     const bool lev_on = flags & IF_LEVELLER_ON;
+    const bool ringflow = PL || lev_on;      // samples travel through the ring (always, with per-lane images)
     int32_t xl[T], xr[T];
     uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * ROW + col;
     const int nq = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
     const int32_t unity = 1 << 28;
 
     int32_t ol[T], orr[T];
-    if (lev_on && do_item) {
-        if (cq == 0) {
+    if (ringflow && do_item) {
+        if (lev_on && cq == 0) {
             const int32_t d = wsub(m.g_cur, m.g_prev);
             if (g.B == 1) { m.p2_base = m.g_cur; m.p2_D = 0; m.p2_R = 0; }
             else { const int32_t mm = (int32_t)g.B - 1; m.p2_base = m.g_prev; m.p2_D = d / mm; m.p2_R = d % mm; }
             m.p2_acc = 0; m.p2_carry = 0;
         }
-        const uint32_t back = (flags & IF_LOOKAHEAD) ? (uint32_t)kLookahead : 0u;
+        const uint32_t back = (lev_on && (flags & IF_LOOKAHEAD)) ? (uint32_t)kLookahead : 0u;
         const uint32_t base = (m.rp2 + cq * T - back) & (kRingLen - 1);
         const bool flat = __all(base + T <= (uint32_t)kRingLen);
         const uint32_t *rl = ring + (size_t)base * ROW;
@@ -823,13 +850,13 @@ __device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, cons
             }
         }
         // ---- loudness (usb_audio.c:1017-1047) and master EQ (:1049-1055) ----
-        run_bands_q28<TAIL, 2>(xl, n, img->loud, lds_state + (sm.loud + 0) * kLanes + lane);
-        run_bands_q28<TAIL, 2>(xr, n, img->loud, lds_state + (sm.loud + 4) * kLanes + lane);
+        run_bands_q28<TAIL, 2>(xl, n, &img->loud[0], lds_state + (sm.loud + 0) * kLanes + lane);
+        run_bands_q28<TAIL, 2>(xr, n, &img->loud[0], lds_state + (sm.loud + 4) * kLanes + lane);
         if (!(flags & IF_BYPASS_MASTER_EQ)) {
-            if (!(img->ch_bypassed & 1u)) run_bands_q28<TAIL, kBands>(xl, n, img->eq[0], lds_state + (sm.eq + 0) * kLanes + lane);
-            if (!(img->ch_bypassed & 2u)) run_bands_q28<TAIL, kBands>(xr, n, img->eq[1], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
+            if (!(img->ch_bypassed & 1u)) run_bands_q28<TAIL, kBands>(xl, n, &img->eq[0][0], lds_state + (sm.eq + 0) * kLanes + lane);
+            if (!(img->ch_bypassed & 2u)) run_bands_q28<TAIL, kBands>(xr, n, &img->eq[1][0], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
         }
-        if (lev_on) {
+        if (ringflow) {
             // ---- leveller pass 1 (leveller.c:282-302) ----
             const int32_t aq = img->lv_alpha_rms_q28, naq = unity - aq;
             const uint32_t base = (m.rp1 + c1 * T) & (kRingLen - 1);
@@ -838,18 +865,22 @@ __device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, cons
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
-                const int32_t ql = qmul(xl[i], xl[i]), qr = qmul(xr[i], xr[i]);
-                m.env_l = wadd(qmul(aq, m.env_l), qmul(naq, ql));
-                m.env_r = wadd(qmul(aq, m.env_r), qmul(naq, qr));
+                if (lev_on) {
+                    const int32_t ql = qmul(xl[i], xl[i]), qr = qmul(xr[i], xr[i]);
+                    m.env_l = wadd(qmul(aq, m.env_l), qmul(naq, ql));
+                    m.env_r = wadd(qmul(aq, m.env_r), qmul(naq, qr));
+                }
                 if (flat) { wl[i * ROW] = (uint32_t)xl[i]; wl[(kRingLen + i) * ROW] = (uint32_t)xr[i]; }
                 else { uint32_t pos = (base + i) & (kRingLen - 1); ring[(size_t)pos * ROW] = (uint32_t)xl[i]; ring[(size_t)(kRingLen + pos) * ROW] = (uint32_t)xr[i]; }
             }
             if (c1 == g.cpb - 1) {   // leveller.c:304-334
-                const float inv = 1.0f / (float)(1 << 28);
-                const float el = (float)m.env_l * inv, er = (float)m.env_r * inv;
-                const float gl = leveller_block_gain(img, m.gsm_db, el > er ? el : er, g.B);
-                m.g_prev = m.g_cur;
-                m.g_cur = f2i_sat(gl * (float)(1 << 28));
+                if (lev_on) {
+                    const float inv = 1.0f / (float)(1 << 28);
+                    const float el = (float)m.env_l * inv, er = (float)m.env_r * inv;
+                    const float gl = leveller_block_gain(img, m.gsm_db, el > er ? el : er, g.B);
+                    m.g_prev = m.g_cur;
+                    m.g_cur = f2i_sat(gl * (float)(1 << 28));
+                }
                 m.rp1 = (m.rp1 + g.B) & (kRingLen - 1);
             }
         }
@@ -881,8 +912,11 @@ __device__ __forceinline__ void master_step_q28(const KArgs &a, ImgPtr img, cons
             if (m.p2_acc >= mm && mm > 0) { m.p2_acc -= mm; m.p2_carry += 1; }
             else if (m.p2_acc <= -mm && mm > 0) { m.p2_acc += mm; m.p2_carry -= 1; }
         }
-        if (cq == g.cpb - 1) m.rp2 = (m.rp2 + g.B) & (kRingLen - 1);
+    } else if (ringflow) {      // per-lane images, leveller bypassed on this lane: the samples pass through
+#pragma unroll
+        for (int i = 0; i < T; ++i) { if (TAIL && i >= nq) break; xl[i] = ol[i]; xr[i] = orr[i]; }
     }
+    if (ringflow && cq == g.cpb - 1) m.rp2 = (m.rp2 + g.B) & (kRingLen - 1);
     // ---- PASS 3: master peaks + crossfeed (usb_audio.c:1065-1073, crossfeed.c:161-180) ----
     if (cq == 0) { m.pk_l = 0; m.pk_r = 0; }
     const bool xf = flags & IF_CROSSFEED_ON;
@@ -926,8 +960,8 @@ struct OutQ28 {
     uint32_t clip;
 };
 
-template <bool TAIL>
-__device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, const StateMap &sm, const Geo &g, OutQ28 &s,
+template <bool TAIL, class IMG>
+__device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const StateMap &sm, const Geo &g, OutQ28 &s,
                                                 int32_t *__restrict__ lds_state, int32_t *__restrict__ lds_pk, const int32_t *__restrict__ xch_base,
                                                 uint32_t wg, uint32_t lane, uint32_t stream, int o_first, int o_count, uint32_t kq, uint32_t cq, uint32_t q) {
     constexpr uint32_t ROW = make_state_map(0).row;
@@ -1003,7 +1037,7 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
             if (enabled) {
                 const int ch = 2 + o;
                 if (!muted && !(flags & IF_BYPASS_MASTER_EQ) && !((img->ch_bypassed >> ch) & 1u))
-                    run_bands_q28<TAIL, kBands>(x, n, img->eq[ch], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
+                    run_bands_q28<TAIL, kBands>(x, n, &img->eq[ch][0], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
                 const int32_t gain = muted ? 0 : f2i_sat(img->out_gain_lin[o] * (float)s.vmm);
 #pragma unroll
                 for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; const int32_t y = q15mul(x[i], gain); x[i] = (gain == 0) ? 0 : y; }
@@ -1092,7 +1126,8 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, ImgPtr img, cons
 // ==========================================================================================
 // the one-stream-per-lane kernel (Q28 flavour; float flavour: lanes whose two streams differ in image)
 // ==========================================================================================
-template <int FLAVOR, bool TAIL>
+// PL (Q28 only; the float instantiation is always per-lane): per-lane parameter images for rows with several presets
+template <int FLAVOR, bool TAIL, bool PL = false>
 __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     constexpr StateMap sm = make_state_map(FLAVOR);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1117,7 +1152,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     asm volatile("s_mov_b64 exec, %0" ::"s"(item.mask) : "memory");
     constexpr bool active = true;
     ImgPtr img = to_const(a.img + item.image);                                   // Q28: the workgroup's image (scalar loads)
-    const DevImage *img_l = a.img + (FLAVOR ? a.stream_image[stream] : 0u);      // float: this lane's own image (vector loads)
+    const DevImage *img_l = a.img + ((FLAVOR || PL) ? a.stream_image[stream] : 0u);   // float / Q28 PL: this lane's own image (vector loads)
 
     uint32_t *gs = a.state + (size_t)wg * sm.n_slots * ROW + col;
     for (int s = wave; s < sm.lds_slots; s += 4) lds[s * kLanes + lane] = gs[(size_t)s * ROW];
@@ -1128,7 +1163,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     g.cpb = (g.B + T - 1) / T;
     g.items = g.n_blocks * g.cpb;
     // float (per-lane images): the schedule cannot depend on one lane's flags, every lane goes through the ring
-    g.lag = FLAVOR ? g.cpb : ((img->flags & IF_LEVELLER_ON) ? g.cpb : 0u);
+    g.lag = (FLAVOR || PL) ? g.cpb : ((img->flags & IF_LEVELLER_ON) ? g.cpb : 0u);
     g.steps = g.items + g.lag + 1;
 
     if (wave == 0 && FLAVOR == 0) {
@@ -1147,7 +1182,10 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             const bool do_p1 = st < g.items;
             const bool do_item = st >= g.lag && st < g.items + g.lag;
             const uint32_t q = st - g.lag;
-            if (do_p1 || do_item) master_step_q28<TAIL>(a, img, sm, g, m, qstate, qxch, wg, lane, stream, do_p1, k1, c1, do_item, kq, cq, q);
+            if (do_p1 || do_item) {
+                if (PL) master_step_q28<TAIL, true>(a, img_l, sm, g, m, qstate, qxch, wg, lane, stream, do_p1, k1, c1, do_item, kq, cq, q);
+                else master_step_q28<TAIL, false>(a, img, sm, g, m, qstate, qxch, wg, lane, stream, do_p1, k1, c1, do_item, kq, cq, q);
+            }
             if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
             if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
             lds_barrier();
@@ -1174,7 +1212,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
-                output_item_q28<TAIL>(a, img, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
+                if (PL) output_item_q28<TAIL>(a, img_l, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
+                else output_item_q28<TAIL>(a, img, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
             lds_barrier();
@@ -1326,18 +1365,18 @@ size_t chain_lds_bytes(int flavor, int packed) {
     return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox : 0)) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);
 }
 
-template <int FLAVOR>
+template <int FLAVOR, bool PL>
 static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(FLAVOR, 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, false, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, true, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<FLAVOR, true>), dim3(n_items), dim3(256), lds, stream, args);
-    else hipLaunchKernelGGL((chain_kernel<FLAVOR, false>), dim3(n_items), dim3(256), lds, stream, args);
+    if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<FLAVOR, true, PL>), dim3(n_items), dim3(256), lds, stream, args);
+    else hipLaunchKernelGGL((chain_kernel<FLAVOR, false, PL>), dim3(n_items), dim3(256), lds, stream, args);
     return hipGetLastError();
 }
 
@@ -1368,14 +1407,10 @@ static hipError_t launch_chain_pk(const KArgs &args, bool leveller_on, uint32_t 
 }
 
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream) {
-    if (!flavor) return launch_chain_t<0>(args, n_items, stream);
-    if (!packed) return launch_chain_t<1>(args, n_items, stream);
-    if (getenv("DSPI_NO_PACKED")) {      // development switch: lane pairs through the one-stream kernel, one component at a time
-        KArgs a0 = args, a1 = args;
-        a0.comp = 0; a1.comp = 1;
-        hipError_t e = launch_chain_t<1>(a0, n_items, stream);
-        return e != hipSuccess ? e : launch_chain_t<1>(a1, n_items, stream);
-    }
+    // packed: 0 = one stream per lane, workgroup-uniform image (Q28) | 1 = packed float kernel | 2 = one stream per lane,
+    // per-lane images (float always; Q28 rows with several presets)
+    if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
+    if (packed != 1) return launch_chain_t<1, false>(args, n_items, stream);
     return launch_chain_pk(args, leveller_on, n_items, stream);
 }
 

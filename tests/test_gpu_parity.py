@@ -171,15 +171,16 @@ def test_many_presets_one_process_call(flavor):
     d.close()
 
 
-@pytest.mark.parametrize("fs,B,depth,S", [(48000, 48, 16, 200), (44100, 45, 24, 70)])
-def test_every_stream_its_own_preset(fs, B, depth, S):
-    """every float stream carries a different preset — different band kinds at the same band index (SVF
+@pytest.mark.parametrize("flavor,fs,B,depth,S", [(1, 48000, 48, 16, 200), (1, 44100, 45, 24, 70), (0, 48000, 48, 16, 150), (0, 44100, 44, 24, 70)])
+def test_every_stream_its_own_preset(flavor, fs, B, depth, S):
+    """every stream (both flavours) carries a different preset — different band kinds at the same band index (SVF
     forms vs biquad, bypassed), leveller / crossfeed / loudness on or off, muted and disabled outputs, delays from 0 to
     the alias value, different preamps.  The one-stream float kernel reads per-lane parameter images, so this is two
     launches, not one per preset; every stream must still match its own oracle, across two calls."""
     blocks = 8
-    d = Dspi(1, S, device=0); o = [Oracle(1, detmath=True) for _ in range(S)]
-    blob = WL.full_chain_blob(1)
+    d = Dspi(flavor, S, device=0); o = [Oracle(flavor, detmath=True) for _ in range(S)]
+    blob = WL.full_chain_blob(flavor)
+    C_, N_ = (11, 9) if flavor else (7, 5)
     for x in [d] + o:
         x.set_rate(fs); x.set_volume(-9 * 256); x.load_bulk(blob)
     R = W.REQ
@@ -188,14 +189,14 @@ def test_every_stream_its_own_preset(fs, B, depth, S):
     types = [W.FILTER_PEAKING, W.FILTER_LOWSHELF, W.FILTER_HIGHSHELF, W.FILTER_LOWPASS, W.FILTER_HIGHPASS, W.FILTER_FLAT]
     for s_ in range(S):
         reqs = [(R["SET_PREAMP"], 0, f(-15.0 + 0.1 * s_))]
-        ch, band = int(rng.integers(0, 11)), int(rng.integers(0, 10))
+        ch, band = int(rng.integers(0, C_)), int(rng.integers(0, 10))
         freq = float(rng.choice([60.0, 400.0, 3000.0, 9000.0, 15000.0]))          # < 6.4 kHz: SVF, above: biquad (48 kHz)
         reqs.append((R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, band, types[s_ % len(types)], 0, freq, 0.9, float(rng.uniform(-6, 6)))))
         if s_ % 3 == 0: reqs.append((R["SET_LEVELLER_ENABLE"], 0, b"\x00"))
         if s_ % 4 == 1: reqs.append((R["SET_CROSSFEED"], 0, b"\x00"))
-        if s_ % 5 == 2: reqs.append((R["SET_OUTPUT_MUTE"], int(rng.integers(0, 9)), b"\x01"))
-        if s_ % 7 == 3: reqs.append((R["SET_OUTPUT_ENABLE"], int(rng.integers(2, 8)), b"\x00"))
-        reqs.append((R["SET_OUTPUT_DELAY"], int(rng.integers(0, 8)), f(float(rng.choice([0.0, 0.1, 0.3, 7.7, 85.0])))))
+        if s_ % 5 == 2: reqs.append((R["SET_OUTPUT_MUTE"], int(rng.integers(0, N_)), b"\x01"))
+        if s_ % 7 == 3: reqs.append((R["SET_OUTPUT_ENABLE"], int(rng.integers(2, N_ - 1)), b"\x00"))
+        reqs.append((R["SET_OUTPUT_DELAY"], int(rng.integers(0, N_ - 1)), f(float(rng.choice([0.0, 0.1, 0.3, 7.7, 42.0 if not flavor else 85.0])))))
         for req, wv, pl in reqs:
             assert d.vendor_set(req, wv, pl, stream=s_) == o[s_].vendor_set(req, wv, pl)
     pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
