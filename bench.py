@@ -88,6 +88,12 @@ def cpu_baseline(fs: int, block_len: int, budget_s: float = 12.0):
         o.set_rate(fs); o.set_volume(-20 * 256)
         assert o.load_bulk(blob) == 0
         oracles.append(o)
+    # (i) one stream on one core, ~2 s
+    t0 = time.perf_counter(); n1 = 0
+    while time.perf_counter() - t0 < 2.0:
+        oracles[0].process(pcm, blocks, block_len, want_peaks=False); n1 += blocks * block_len
+    single = n1 / (time.perf_counter() - t0)
+    # (ii) one independent stream per hardware thread
     counts = [0] * cores
     stop = time.perf_counter() + budget_s
 
@@ -108,6 +114,7 @@ def cpu_baseline(fs: int, block_len: int, budget_s: float = 12.0):
         "sample": f"{cores} threads x 1 stream each, config-3 chain, {frames // cores} frames/thread in {dt:.1f} s "
                   f"({'reference leaf C (oracle/_ref) under the restated orchestrator' if use_ref else 'oracle restatement'}, gcc -O3, FTZ|DAZ)",
         "frames_per_s": frames / dt,
+        "single_core_frames_per_s": single, "single_core_realtime_x": single / fs,
     }
 
 
