@@ -58,3 +58,15 @@ run('  ... + everything flat (I/O skeleton only)', b3, outputs=False)
 run('everything flat, with outputs', b3)
 b4 = full.copy(); b4['outputs']['enabled'][2:] = 0
 run('full chain, only outputs 0-1 enabled', b4)
+b = full.copy(); b['eq']['type'][0:2] = 0
+run('full chain, master EQ flat', b)
+b = full.copy(); b['global_']['loudness_enabled'] = 0
+run('full chain, loudness off', b)
+b = full.copy(); b['eq']['type'][0:2] = 0; b['global_']['loudness_enabled'] = 0
+run('full chain, master EQ flat + loudness off', b)
+b = full.copy(); b['eq']['type'][2:] = 0
+run('full chain, output EQ flat', b)
+b = full.copy(); b['eq']['type'][2:, 5:] = 0
+run('full chain, output EQ bands 5-9 flat', b)
+b = full.copy(); b['crossfeed']['enabled'] = 0
+run('full chain, crossfeed off', b)
