@@ -110,18 +110,9 @@ def pk_line(op, d, a, b, i):
     return "v_pk_%s_f32 %s, %s, %s%s" % ('mul' if op == 'mul' else 'add', dn, an, bn, mods)
 
 
-def block_pk(kind):
-    # instances with concrete register names for hazard analysis
-    inst = []
-    for i in range(T):
-        for (op, d, a, b) in ops(kind):
-            def phys(n):
-                if n == 'x':
-                    return 'x%d' % i
-                if n[0] == 't':
-                    return 't%d_%s' % (i % NTSETS, n[1])
-                return n
-            inst.append(dict(text=pk_line(op, d, a, b, i), w=phys(d), r=[phys(a), phys(b)]))
+def schedule(inst, lat_slots):
+    """List scheduling of `inst` (dicts with text / w / r): a dependent packed op wants >= lat_slots issue slots after
+    its producer; ties go to the longest remaining critical path; bounded look-ahead keeps the schedule local."""
     n = len(inst)
     preds = [set() for _ in range(n)]      # (j, is_raw)
     last_w = {}
@@ -146,7 +137,7 @@ def block_pk(kind):
     # critical path (in slots) to the end of the block
     cp = [0] * n
     for k in range(n - 1, -1, -1):
-        cp[k] = 1 + max([cp[s] + (LAT_SLOTS - 1 if raw else 0) for (s, raw) in succs[k]] or [0])
+        cp[k] = 1 + max([cp[s] + (lat_slots - 1 if raw else 0) for (s, raw) in succs[k]] or [0])
     done_slot = {}
     order = []
     slot = 0
@@ -156,7 +147,7 @@ def block_pk(kind):
         for k in sorted(remaining):
             if any(j not in done_slot for (j, _) in preds[k]):
                 continue
-            est = max([done_slot[j] + (LAT_SLOTS if raw else 1) for (j, raw) in preds[k]] or [0])
+            est = max([done_slot[j] + (lat_slots if raw else 1) for (j, raw) in preds[k]] or [0])
             key = (max(est, slot), -cp[k], k)
             if best is None or key < best[0]:
                 best = (key, k)
@@ -168,7 +159,156 @@ def block_pk(kind):
         slot += 1
         order.append(k)
         remaining.discard(k)
-    return [inst[k]['text'] for k in order]
+    return [inst[k]['text'] for k in order], slot
+
+
+def block_pk(kind):
+    # instances with concrete register names for hazard analysis
+    inst = []
+    for i in range(T):
+        for (op, d, a, b) in ops(kind):
+            def phys(n):
+                if n == 'x':
+                    return 'x%d' % i
+                if n[0] == 't':
+                    return 't%d_%s' % (i % NTSETS, n[1])
+                return n
+            inst.append(dict(text=pk_line(op, d, a, b, i), w=phys(d), r=[phys(a), phys(b)]))
+    return schedule(inst, LAT_SLOTS)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# dual packed family: the SAME band kind on two independent channels (master EQ left / right), interleaved.
+# One channel alone is latency-bound (a biquad's s1 -> y -> a1*y -> ... -> s1 loop is 4 dependent ops = ~64 cycles
+# per sample against 36 cycles of issue); two interleaved chains keep a wave that has a SIMD to itself issuing.
+# ---------------------------------------------------------------------------------------------------------
+NTSETS2 = int(os.environ.get('BL_NTSETS2', 1))
+LAT_SLOTS2 = int(os.environ.get('BL_LAT2', 4))
+
+
+def pk_operand2(n, i, ch):
+    if n == 'x':
+        return '%%[x%s%d]' % (ch, i), ''
+    if n in ('s1', 's2'):
+        return '%%[%s%s]' % (n, ch), ''
+    if n[0] == 't':
+        return '%%[t%s%d_%s]' % (ch, i % NTSETS2, n[1]), ''
+    c = int(n[1])
+    return '%%[%s%d%d]' % (ch, c & ~1, c | 1), ('lo' if c % 2 == 0 else 'hi')
+
+
+def pk_line2(op, d, a, b, i, ch):
+    dn, _ = pk_operand2(d, i, ch)
+    an, asel = pk_operand2(a, i, ch)
+    bn, bsel = pk_operand2(b, i, ch)
+    assert not bsel
+    if op == 'fma2':
+        return "v_pk_fma_f32 %s, %%[two], %s, %s neg_lo:[0,0,1] neg_hi:[0,0,1]" % (dn, an, bn)
+    mods = ''
+    if asel == 'lo':
+        mods += ' op_sel_hi:[0,1]'
+    elif asel == 'hi':
+        mods += ' op_sel:[1,0]'
+    if op == 'sub':
+        mods += ' neg_lo:[0,1] neg_hi:[0,1]'
+    return "v_pk_%s_f32 %s, %s, %s%s" % ('mul' if op == 'mul' else 'add', dn, an, bn, mods)
+
+
+def block_pk2(kind):
+    inst = []
+    for i in range(T):
+        for ch in 'ab':
+            for (op, d, a, b) in ops(kind):
+                def phys(n):
+                    if n == 'x':
+                        return 'x%s%d' % (ch, i)
+                    if n[0] == 't':
+                        return 't%s%d_%s' % (ch, i % NTSETS2, n[1])
+                    if n in ('s1', 's2'):
+                        return n + ch
+                    return ch + n
+                inst.append(dict(text=pk_line2(op, d, a, b, i, ch), w=phys(d), r=[phys(a), phys(b)]))
+    lines, slots = schedule(inst, LAT_SLOTS2)
+    if os.environ.get('BL_VERBOSE'):
+        print("dual %s: %d instructions in %d slots" % (kind, len(inst), slots))
+    return lines
+
+
+def block_pk1of2(kind, ch):
+    """One channel of the pair on its own (the two channels' kinds differ): the single-channel schedule on this channel's
+    operands, with both channels' temporaries as its rotating sets."""
+    other = 'b' if ch == 'a' else 'a'
+    sets = [(c, k) for k in range(NTSETS2) for c in (ch, other)]
+
+    def tname(i, j):
+        c, k = sets[i % len(sets)]
+        return 't%s%d_%s' % (c, k, j)
+    inst = []
+    for i in range(T):
+        for (op, d, a, b) in ops(kind):
+            def phys(n):
+                if n == 'x':
+                    return 'x%s%d' % (ch, i)
+                if n[0] == 't':
+                    return tname(i, n[1])
+                if n in ('s1', 's2'):
+                    return n + ch
+                return ch + n
+
+            def opnd(n):
+                if n[0] == 't':
+                    return '%%[%s]' % tname(i, n[1]), ''
+                return pk_operand2(n, i, ch)
+            dn, _ = opnd(d)
+            an, asel = opnd(a)
+            bn, _ = opnd(b)
+            if op == 'fma2':
+                text = "v_pk_fma_f32 %s, %%[two], %s, %s neg_lo:[0,0,1] neg_hi:[0,0,1]" % (dn, an, bn)
+            else:
+                mods = ''
+                if asel == 'lo':
+                    mods += ' op_sel_hi:[0,1]'
+                elif asel == 'hi':
+                    mods += ' op_sel:[1,0]'
+                if op == 'sub':
+                    mods += ' neg_lo:[0,1] neg_hi:[0,1]'
+                text = "v_pk_%s_f32 %s, %s, %s%s" % ('mul' if op == 'mul' else 'add', dn, an, bn, mods)
+            inst.append(dict(text=text, w=phys(d), r=[phys(a), phys(b)]))
+    return schedule(inst, LAT_SLOTS)[0]
+
+
+def emit_dual(name, kinds, out):
+    """Two channels in ONE asm statement (a single in-place update of both sample arrays for the register allocator):
+    equal kinds run the interleaved loops, different kinds (or one channel bypassed) run channel a, then channel b."""
+    lines = ["s_cmp_lg_u32 %[ka], %[kb]", "s_cbranch_scc1 .Lsplit_%=", "s_cmp_eq_u32 %[ka], 0", "s_cbranch_scc1 .Lend_%="]
+    for kname, kval in kinds[:-1]:
+        lines += ["s_cmp_eq_u32 %%[ka], %d" % kval, "s_cbranch_scc1 .L%s_%%=" % kname]
+    lines += block_pk2(kinds[-1][0]) + ["s_branch .Lend_%="]
+    for kname, kval in kinds[:-1]:
+        lines += [".L%s_%%=:" % kname] + block_pk2(kname) + ["s_branch .Lend_%="]
+    for ch, nxt in (('a', '.Lsplitb_%='), ('b', '.Lend_%=')):
+        lines += [(".Lsplit_%=:" if ch == 'a' else ".Lsplitb_%=:"), "s_cmp_eq_u32 %%[k%s], 0" % ch, "s_cbranch_scc1 %s" % nxt]
+        for kname, kval in kinds[:-1]:
+            lines += ["s_cmp_eq_u32 %%[k%s], %d" % (ch, kval), "s_cbranch_scc1 .L%s%s_%%=" % (ch, kname)]
+        lines += block_pk1of2(kinds[-1][0], ch) + ["s_branch %s" % nxt]
+        for kname, kval in kinds[:-1]:
+            lines += [".L%s%s_%%=:" % (ch, kname)] + block_pk1of2(kname, ch) + ["s_branch %s" % nxt]
+    lines += [".Lend_%=:"]
+    body = '\n'.join('        "%s\\n\\t"' % l for l in lines)
+    xs = ', '.join('[x%s%d] "+v"(x%s[%d])' % (ch, i, ch, i) for ch in 'ab' for i in range(T))
+    tn = ['t%s%d_%d' % (ch, s_, j) for ch in 'ab' for s_ in range(NTSETS2) for j in range(4)]
+    ts = ', '.join('[%s] "=&v"(%s)' % (t, t) for t in tn)
+    out.append("__device__ __forceinline__ void %s(v2f (&xa)[16], v2f (&xb)[16], v2f &s1a, v2f &s2a, v2f &s1b, v2f &s2b, uint32_t ka, uint32_t kb,\n"
+               "        v2f a01, v2f a23, v2f a45, v2f b01, v2f b23, v2f b45) {" % name)
+    out.append("    v2f %s;" % ', '.join(tn))
+    out.append("    const v2f two = {2.0f, 2.0f};")
+    out.append("    asm volatile(")
+    out.append(body)
+    out.append("        : %s, [s1a] \"+v\"(s1a), [s2a] \"+v\"(s2a), [s1b] \"+v\"(s1b), [s2b] \"+v\"(s2b), %s" % (xs, ts))
+    out.append("        : [ka] \"s\"(ka), [kb] \"s\"(kb), [a01] \"s\"(a01), [a23] \"s\"(a23), [a45] \"s\"(a45), [b01] \"s\"(b01), [b23] \"s\"(b23), [b45] \"s\"(b45), [two] \"s\"(two)")
+    out.append("        : \"scc\");")
+    out.append("}")
+    out.append("")
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -263,6 +403,8 @@ def main():
         if packed:
             emit_tail("band16pk_any_tail", allk, out)
             emit_tail("band16pk_shelf_tail", [('SH', 5)], out)
+            emit_dual("band16pk2_any", allk, out)            # master EQ, left + right interleaved (same kind in both)
+            emit_dual("band16pk2_shelf", [('SH', 5)], out)   # loudness, left + right
         path = os.path.join(here, fname)
         open(path, "w").write('\n'.join(out))
         print("wrote", os.path.normpath(path))
