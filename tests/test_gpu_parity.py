@@ -73,6 +73,25 @@ def test_full_chain(flavor, fs, B, depth):
 
 
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+@pytest.mark.parametrize("lev", [1, 0])
+def test_ragged_packets_delay_edges(flavor, lev):
+    """44/45-frame packets (short last chunk) with the delay-line corner cases: delays shorter than a chunk (per-sample
+    order), zero, and the maximum (a delay of MAX samples aliases to 0, SURVEY.md a12); one output disabled, one muted;
+    leveller on and off (the hand-off runs in the intake wave when it is off); enough packets to wrap the lines."""
+    b = WL.full_chain_blob(flavor)
+    n_out = 9 if flavor else 5
+    max_ms = (4096 if flavor else 2048) * 1000.0 / 44100
+    delays = [0.05, 0.2, 0.3, 0.0, max_ms + 1.0, max_ms - 0.05, 1.0, 0.1, 0.25][:n_out]
+    for o in range(n_out):
+        b["outputs"][o]["delay_ms"] = delays[o]
+    b["outputs"][1]["enabled"] = 0
+    b["outputs"][2]["mute"] = 1
+    b["leveller"]["enabled"] = lev
+    compare(flavor, 44100, 45, 120 if flavor else 60, 20, b, calls=3)
+    compare(flavor, 44100, 44, 30, 9, b, depth=24, calls=2, first_stream=14)
+
+
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_long_run_wraps_delay_lines(flavor):
     """More frames than a delay line holds (4096 float / 2048 Q28 positions): the shared write index wraps, the 80 ms /
     40 ms lines read across the wrap, and the leveller ring (1024) goes round several times; three launches."""

@@ -277,35 +277,41 @@ def block_pk1of2(kind, ch):
     return schedule(inst, LAT_SLOTS)[0]
 
 
-def emit_dual(name, kinds, out):
+def emit_dual(name, kinds, out, with_n=False):
     """Two channels in ONE asm statement (a single in-place update of both sample arrays for the register allocator):
-    equal kinds run the interleaved loops, different kinds (or one channel bypassed) run channel a, then channel b."""
-    lines = ["s_cmp_lg_u32 %[ka], %[kb]", "s_cbranch_scc1 .Lsplit_%=", "s_cmp_eq_u32 %[ka], 0", "s_cbranch_scc1 .Lend_%="]
-    for kname, kval in kinds[:-1]:
-        lines += ["s_cmp_eq_u32 %%[ka], %d" % kval, "s_cbranch_scc1 .L%s_%%=" % kname]
-    lines += block_pk2(kinds[-1][0]) + ["s_branch .Lend_%="]
-    for kname, kval in kinds[:-1]:
-        lines += [".L%s_%%=:" % kname] + block_pk2(kname) + ["s_branch .Lend_%="]
-    for ch, nxt in (('a', '.Lsplitb_%='), ('b', '.Lend_%=')):
-        lines += [(".Lsplit_%=:" if ch == 'a' else ".Lsplitb_%=:"), "s_cmp_eq_u32 %%[k%s], 0" % ch, "s_cbranch_scc1 %s" % nxt]
-        for kname, kval in kinds[:-1]:
-            lines += ["s_cmp_eq_u32 %%[k%s], %d" % (ch, kval), "s_cbranch_scc1 .L%s%s_%%=" % (ch, kname)]
-        lines += block_pk1of2(kinds[-1][0], ch) + ["s_branch %s" % nxt]
-        for kname, kval in kinds[:-1]:
-            lines += [".L%s%s_%%=:" % (ch, kname)] + block_pk1of2(kname, ch) + ["s_branch %s" % nxt]
+    equal kinds run the interleaved loops, different kinds (or one channel bypassed) run channel a, then channel b.
+    with_n: a ragged chunk (n < 16) runs channel a, then channel b, in program order with early exits."""
+    lines = []
+    if with_n:
+        lines += ["s_cmp_lg_u32 %[n], 16", "s_cbranch_scc1 .Ltail_%="]
+    lines += ["s_cmp_lg_u32 %[ka], %[kb]", "s_cbranch_scc1 .Lsplit_%="]
+    lines += dispatch(kinds, block_pk2, 'ka', 'd', '.Lend_%=')
+    lines += [".Lsplit_%=:"] + dispatch(kinds, lambda kind: block_pk1of2(kind, 'a'), 'ka', 'a', '.Lsplitb_%=')
+    lines += [".Lsplitb_%=:"] + dispatch(kinds, lambda kind: block_pk1of2(kind, 'b'), 'kb', 'b', '.Lend_%=')
+    if with_n:
+        def tail_ch(ch, nxt):
+            def blk(kind):
+                ls = []
+                for i in range(T):
+                    ls += ["s_cmp_le_u32 %%[n], %d" % i, "s_cbranch_scc1 %s" % nxt]
+                    ls += [pk_line2(op, d, a, b, i, ch) for (op, d, a, b) in ops(kind)]
+                return ls
+            return blk
+        lines += [".Ltail_%=:"] + dispatch(kinds, tail_ch('a', '.Ltailb_%='), 'ka', 'ta', '.Ltailb_%=')
+        lines += [".Ltailb_%=:"] + dispatch(kinds, tail_ch('b', '.Lend_%='), 'kb', 'tb', '.Lend_%=')
     lines += [".Lend_%=:"]
     body = '\n'.join('        "%s\\n\\t"' % l for l in lines)
     xs = ', '.join('[x%s%d] "+v"(x%s[%d])' % (ch, i, ch, i) for ch in 'ab' for i in range(T))
     tn = ['t%s%d_%d' % (ch, s_, j) for ch in 'ab' for s_ in range(NTSETS2) for j in range(4)]
     ts = ', '.join('[%s] "=&v"(%s)' % (t, t) for t in tn)
     out.append("__device__ __forceinline__ void %s(v2f (&xa)[16], v2f (&xb)[16], v2f &s1a, v2f &s2a, v2f &s1b, v2f &s2b, uint32_t ka, uint32_t kb,\n"
-               "        v2f a01, v2f a23, v2f a45, v2f b01, v2f b23, v2f b45) {" % name)
+               "        v2f a01, v2f a23, v2f a45, v2f b01, v2f b23, v2f b45%s) {" % (name, ", uint32_t n" if with_n else ""))
     out.append("    v2f %s;" % ', '.join(tn))
     out.append("    const v2f two = {2.0f, 2.0f};")
     out.append("    asm volatile(")
     out.append(body)
     out.append("        : %s, [s1a] \"+v\"(s1a), [s2a] \"+v\"(s2a), [s1b] \"+v\"(s1b), [s2b] \"+v\"(s2b), %s" % (xs, ts))
-    out.append("        : [ka] \"s\"(ka), [kb] \"s\"(kb), [a01] \"s\"(a01), [a23] \"s\"(a23), [a45] \"s\"(a45), [b01] \"s\"(b01), [b23] \"s\"(b23), [b45] \"s\"(b45), [two] \"s\"(two)")
+    out.append("        : [ka] \"s\"(ka), [kb] \"s\"(kb), [a01] \"s\"(a01), [a23] \"s\"(a23), [a45] \"s\"(a45), [b01] \"s\"(b01), [b23] \"s\"(b23), [b45] \"s\"(b45), [two] \"s\"(two)%s" % (', [n] \"s\"(n)' if with_n else ''))
     out.append("        : \"scc\");")
     out.append("}")
     out.append("")
@@ -349,22 +355,35 @@ def emit(name, kinds, out, packed, vcoef=False):
     out.append("")
 
 
-def emit_tail(name, kinds, out):
-    """Packed, ragged chunk: same dispatch, samples in program order with a scalar early exit in front of each one
-    (n is wave-uniform: the last chunk of a 44/45-frame packet).  Keeps x[] in registers where the C++ twin with its
-    guarded loops lets the compiler demote the arrays to scratch."""
-    def blk(kind):
-        lines = []
-        for i in range(T):
-            lines += ["s_cmp_le_u32 %%[n], %d" % i, "s_cbranch_scc1 .Lend_%="]
-            lines += [pk_line(op, d, a, b, i) for (op, d, a, b) in ops(kind)]
-        return lines
-    lines = ["s_cmp_eq_u32 %[k], 0", "s_cbranch_scc1 .Lend_%="]
+def dispatch(kinds, blockfn, kreg, tag, nxt):
+    """Scalar dispatch on the band kind held in %[kreg]: kind 0 -> nxt, every block ends with a branch to nxt."""
+    lines = ["s_cmp_eq_u32 %%[%s], 0" % kreg, "s_cbranch_scc1 %s" % nxt]
     for kname, kval in kinds[:-1]:
-        lines += ["s_cmp_eq_u32 %%[k], %d" % kval, "s_cbranch_scc1 .L%s_%%=" % kname]
-    lines += blk(kinds[-1][0]) + ["s_branch .Lend_%="]
+        lines += ["s_cmp_eq_u32 %%[%s], %d" % (kreg, kval), "s_cbranch_scc1 .L%s%s_%%=" % (tag, kname)]
+    lines += blockfn(kinds[-1][0]) + ["s_branch %s" % nxt]
     for kname, kval in kinds[:-1]:
-        lines += [".L%s_%%=:" % kname] + blk(kname) + ["s_branch .Lend_%="]
+        lines += [".L%s%s_%%=:" % (tag, kname)] + blockfn(kname) + ["s_branch %s" % nxt]
+    return lines
+
+
+def tail_block(kind, line_fn):
+    """Ragged chunk: samples in program order with a scalar early exit in front of each one (n is wave-uniform: the
+    last chunk of a 44/45-frame packet)."""
+    lines = []
+    for i in range(T):
+        lines += ["s_cmp_le_u32 %%[n], %d" % i, "s_cbranch_scc1 .Lend_%="]
+        lines += [line_fn(op, d, a, b, i) for (op, d, a, b) in ops(kind)]
+    return lines
+
+
+def emit_n(name, kinds, out):
+    """Packed, full OR ragged chunk in ONE asm statement (kernels for 44.1 kHz packets): n == 16 takes the scheduled loop,
+    n < 16 the program-order loop with early exits.  Two alternative statements would make the register allocator
+    reconcile two placements of x[] at every band."""
+    lines = ["s_cmp_lg_u32 %[n], 16", "s_cbranch_scc1 .Ltail_%="]
+    lines += dispatch(kinds, block_pk, 'k', 'f', '.Lend_%=')
+    lines += [".Ltail_%=:"]
+    lines += dispatch(kinds, lambda kind: tail_block(kind, pk_line), 'k', 't', '.Lend_%=')
     lines += [".Lend_%=:"]
     body = '\n'.join('        "%s\\n\\t"' % l for l in lines)
     xs = ', '.join('[x%d] "+v"(x[%d])' % (i, i) for i in range(T))
@@ -401,10 +420,11 @@ def main():
             emit("band16v_any", allk, out, False, vcoef=True)
             emit("band16v_shelf", [('SH', 5)], out, False, vcoef=True)
         if packed:
-            emit_tail("band16pk_any_tail", allk, out)
-            emit_tail("band16pk_shelf_tail", [('SH', 5)], out)
+            emit_n("band16pk_any_n", allk, out)              # kernels for ragged packets: full or short chunk
             emit_dual("band16pk2_any", allk, out)            # master EQ, left + right interleaved (same kind in both)
             emit_dual("band16pk2_shelf", [('SH', 5)], out)   # loudness, left + right
+            emit_dual("band16pk2_any_n", allk, out, with_n=True)
+            emit_dual("band16pk2_shelf_n", [('SH', 5)], out, with_n=True)
         path = os.path.join(here, fname)
         open(path, "w").write('\n'.join(out))
         print("wrote", os.path.normpath(path))
