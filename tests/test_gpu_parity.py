@@ -92,6 +92,14 @@ def test_ragged_packets_delay_edges(flavor, lev):
 
 
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+@pytest.mark.parametrize("B", [1, 7, 17, 97])
+def test_unusual_packet_lengths(flavor, B):
+    """Packets of 1 frame (the g.B == 1 ramp, leveller.c:213), shorter than a chunk, one frame over a chunk, and the
+    largest the firmware accepts (97); full chain, two launches."""
+    compare(flavor, 48000, B, 200 if B < 4 else 40, 9, WL.full_chain_blob(flavor), calls=2)
+
+
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_long_run_wraps_delay_lines(flavor):
     """More frames than a delay line holds (4096 float / 2048 Q28 positions): the shared write index wraps, the 80 ms /
     40 ms lines read across the wrap, and the leveller ring (1024) goes round several times; three launches."""
