@@ -224,9 +224,6 @@ __device__ __forceinline__ float leveller_block_gain(IMG img, float &gsm_db, flo
 // lives in LDS, so the barrier must drain LDS traffic (lgkmcnt) but NOT the HBM stores/loads in flight:
 // __syncthreads() would add `s_waitcnt vmcnt(0)` and serialise every step behind its own write-backs.
 __device__ __forceinline__ void lds_barrier() {
-#ifdef DSPI_EXP_NOSYNC
-    return;      // timing experiment only: waves free-run (results are garbage)
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
