@@ -29,12 +29,16 @@ __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 __device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
 
+// 256 threads = four waves = one per SIMD of a CU, 256 / row tile rows per workgroup: with two-wave workgroups the
+// dispatcher put both workgroups of a CU on the same two SIMDs and left the other two idle (measured: exactly 2x).
+constexpr int kPdmThreads = 256;
+
 template <bool TILED>
-__global__ __launch_bounds__(128) void pdm_kernel(uint32_t *state, const int32_t *sub, uint32_t *words, uint32_t n_streams, uint32_t n_frames,
-                                                   uint32_t row) {
-    const uint32_t wg = blockIdx.x, col = threadIdx.x;
+__global__ __launch_bounds__(kPdmThreads) void pdm_kernel(uint32_t *state, const int32_t *sub, uint32_t *words, uint32_t n_streams, uint32_t n_frames,
+                                                           uint32_t row) {
+    const uint32_t wg = blockIdx.x * (kPdmThreads / row) + threadIdx.x / row, col = threadIdx.x % row;
     const uint32_t stream = wg * row + col;
-    if (col >= row || stream >= n_streams) return;
+    if (stream >= n_streams) return;
     uint32_t *gs = state + (size_t)wg * kPdmStateWords * row + col;
     int32_t err = (int32_t)gs[0 * row], err2 = (int32_t)gs[1 * row];
     int32_t x1 = (int32_t)gs[2 * row], x2 = (int32_t)gs[3 * row], y1 = (int32_t)gs[4 * row], y2 = (int32_t)gs[5 * row], err_acc = (int32_t)gs[6 * row];
@@ -120,8 +124,9 @@ __global__ void pdm_reset_kernel(uint32_t *state, uint32_t n_streams, uint32_t r
 
 hipError_t launch_pdm(bool tiled, uint32_t *state, const int32_t *sub, uint32_t *words, uint32_t n_streams, uint32_t n_frames, uint32_t row,
                       uint32_t n_wg, hipStream_t stream) {
-    if (tiled) hipLaunchKernelGGL(pdm_kernel<true>, dim3(n_wg), dim3(128), 0, stream, state, sub, words, n_streams, n_frames, row);
-    else hipLaunchKernelGGL(pdm_kernel<false>, dim3(n_wg), dim3(128), 0, stream, state, sub, words, n_streams, n_frames, row);
+    const uint32_t per = kPdmThreads / row, blocks = (n_wg + per - 1) / per;
+    if (tiled) hipLaunchKernelGGL(pdm_kernel<true>, dim3(blocks), dim3(kPdmThreads), 0, stream, state, sub, words, n_streams, n_frames, row);
+    else hipLaunchKernelGGL(pdm_kernel<false>, dim3(blocks), dim3(kPdmThreads), 0, stream, state, sub, words, n_streams, n_frames, row);
     return hipGetLastError();
 }
 
