@@ -177,14 +177,17 @@ int rebuild_launch_lists(dspi_ctx *c) {
             if (k >= 2) {
                 // float: lanes with one stream of an image (k = 2 first, 3 second stream); Q28 (k = 2): rows that hold
                 // several images.  Per-lane parameter kernel: all images of a row merge into one item.
-                if (lev == 0 && (c->flavor || k == 2)) {
-                    std::map<uint32_t, std::pair<uint64_t, int>> rows;      // row -> (lane mask, number of images)
-                    const int src = c->flavor ? k : 0;
-                    for (size_t i = 0; i < c->images.size(); i++)
-                        if (c->image_refs[i] > 0)
-                            for (const WgItem &it : c->image_items[src][i]) { auto &r = rows[it.wg]; r.first |= it.mask; r.second++; }
-                    for (const auto &r : rows)
-                        if (c->flavor || r.second.second > 1) v.push_back(WgItem{r.first, 0u, r.second.first, 0ull});
+                // Float: both lane components go into list 2 (WgItem::image = component), one launch.
+                if (lev == 0 && k == 2) {
+                    for (int comp = 0; comp < (c->flavor ? 2 : 1); comp++) {
+                        std::map<uint32_t, std::pair<uint64_t, int>> rows;      // row -> (lane mask, number of images)
+                        const int src = c->flavor ? 2 + comp : 0;
+                        for (size_t i = 0; i < c->images.size(); i++)
+                            if (c->image_refs[i] > 0)
+                                for (const WgItem &it : c->image_items[src][i]) { auto &r = rows[it.wg]; r.first |= it.mask; r.second++; }
+                        for (const auto &r : rows)
+                            if (c->flavor || r.second.second > 1) v.push_back(WgItem{r.first, (uint32_t)comp, r.second.first, 0ull});
+                    }
                 }
             } else {
                 std::map<uint32_t, int> per_row;       // Q28: rows with one image keep the workgroup-uniform path
@@ -565,19 +568,18 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.img = c->d_images;
     a.stream_image = c->d_stream_image;
     // float flavour: lanes with both streams on one image go to the packed kernel (list 1), every other lane to the
-    // per-lane-parameter kernel, once per lane component (lists 2, 3).  Q28: rows with one image run workgroup-uniform
+    // per-lane-parameter kernel for both lane components in one launch (list 2).  Q28: rows with one image run workgroup-uniform
     // (list 0), rows with several in per-lane-parameter mode (list 2).  A launch covers every image.
-    struct Launch { int list; int packed; uint32_t comp; };
-    static const Launch kF32[] = {{1, 1, 0}, {2, 2, 0}, {3, 2, 1}};
-    static const Launch kQ28[] = {{0, 0, 0}, {2, 2, 0}};
+    struct Launch { int list; int packed; };
+    static const Launch kF32[] = {{1, 1}, {2, 2}};
+    static const Launch kQ28[] = {{0, 0}, {2, 2}};
     const Launch *ls = c->flavor ? kF32 : kQ28;
-    const int nl = c->flavor ? 3 : 2;
+    const int nl = 2;
     for (int lev = 0; lev < 2; lev++)
         for (int l = 0; l < nl; l++) {
             const auto &items = c->launch_items[lev][ls[l].list];
             if (items.empty()) continue;
             a.items = c->d_litems + c->launch_item_offset[lev][ls[l].list];
-            a.comp = ls[l].comp;
             hipError_t e = launch_chain(c->flavor, ls[l].packed, lev != 0, a, (uint32_t)items.size(), c->hs);
             if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
             if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));

@@ -20,7 +20,6 @@ struct KArgs {
     int32_t *sub;            // [stream][frames] or null
     uint16_t *peaks;         // [stream][block][C] or null
     uint32_t n_streams, n_blocks, block_len, bit_depth;
-    uint32_t comp;           // float flavour, scalar kernel: which of a lane's two streams (column = lane*2 + comp)
     const uint32_t *stream_image;   // [n_streams] image index of every stream (float one-stream kernel: per-lane parameters)
     uint32_t tiled_out;      // DSPI_OUT_TILED: pairs = [tile][output][frames][row], sub = [tile][frames][row] (row = StateMap::row)
 };
@@ -28,7 +27,7 @@ struct KArgs {
 size_t chain_lds_bytes(int flavor, int packed);
 // packed: 1 = packed float kernel (items list lanes whose two streams share the item's image); 0 = one stream per lane
 // with the item's image for the whole workgroup (Q28); 2 = one stream per lane, every lane its own image
-// (args.stream_image; float: the stream args.comp of each listed lane; Q28: rows with several presets)
+// (args.stream_image; float: stream WgItem::image (0 / 1) of each listed lane; Q28: rows with several presets)
 // leveller_on: IF_LEVELLER_ON of every image in args.items (the host groups them; the packed kernel is specialised on it)
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,

@@ -1140,9 +1140,10 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // the float flavour keeps two streams per lane column pair (packed kernel); this scalar kernel then serves one
-    // component (a.comp) of the lanes whose two streams carry different parameter images
+    // component (item.image: 0 = first, 1 = second stream of the lane; per-lane parameter mode has no use for an image
+    // index) of the lanes whose two streams carry different parameter images — both components in one launch
     constexpr uint32_t ROW = sm.row;
-    const uint32_t col = FLAVOR ? lane * 2 + a.comp : lane;
+    const uint32_t col = FLAVOR ? lane * 2 + (item.image & 1u) : lane;
     const uint32_t stream = wg * ROW + col;
     // Lanes that are not part of this launch (streams of another parameter image, or padding past n_streams; the
     // host never sets those mask bits) are switched off ONCE by narrowing EXEC for the whole kernel: every vector

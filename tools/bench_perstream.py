@@ -31,5 +31,5 @@ t0 = time.perf_counter()
 for s in range(S):
     d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s), stream=s)
 print(f"host: {S} per-stream parameter images in {time.perf_counter() - t0:.1f} s", flush=True)
-timed(f"{S} streams, {S} presets (per-lane kernel, 2 launches)")
+timed(f"{S} streams, {S} presets (per-lane kernel)")
 d.close()
