@@ -415,7 +415,8 @@ def main():
         out = [HEADER[0] % fname] + HEADER[1:] + [note, ""]
         pre = "band16pk" if packed else "band16"
         emit(pre + "_any", allk, out, packed)
-        emit(pre + "_shelf", [('SH', 5)], out, packed)      # loudness stages are shelves (or bypassed)
+        if not packed:
+            emit(pre + "_shelf", [('SH', 5)], out, packed)      # loudness stages are shelves (or bypassed)
         if not packed:      # per-lane parameter kernel: coefficients are per-lane values (VGPRs), the kind is wave-uniform here
             emit("band16v_any", allk, out, False, vcoef=True)
             emit("band16v_shelf", [('SH', 5)], out, False, vcoef=True)
