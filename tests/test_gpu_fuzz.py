@@ -75,3 +75,83 @@ def test_random_presets(flavor, seed):
     blob = random_blob(rng, flavor, fs)
     compare(flavor, fs, B, 2 * int(rng.integers(6, 20)), S, blob, vol=vol, depth=depth, calls=2,
             check_streams=sorted(set(int(x) for x in rng.integers(0, S, 6))), first_stream=int(rng.integers(0, 40)))
+
+
+def random_request(rng, flavor, fs):
+    """One random SET request of the DSP subset (config.h:111-251) with an in-range or deliberately out-of-range payload."""
+    import struct
+    C, N, _, _, _ = W.dims(flavor)
+    R = W.REQ
+    f = lambda v: struct.pack("<f", float(v))
+    pick = int(rng.integers(0, 22))
+    if pick == 0:
+        ch, band = int(rng.integers(0, C)), int(rng.integers(0, 10))
+        return R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, band, int(rng.integers(0, 6)), 0, float(np.exp(rng.uniform(np.log(15), np.log(0.48 * fs)))),
+                                                 float(np.exp(rng.uniform(np.log(0.08), np.log(25)))), float(rng.uniform(-12, 12)))
+    if pick == 1: return R["SET_PREAMP"], 0, f(rng.uniform(-20, 8))
+    if pick == 2: return R["SET_BYPASS"], 0, bytes([int(rng.integers(0, 2))])
+    if pick == 3: return R["SET_LOUDNESS"], 0, bytes([int(rng.integers(0, 2))])
+    if pick == 4: return R["SET_LOUDNESS_REF"], 0, f(rng.uniform(60, 100))
+    if pick == 5: return R["SET_LOUDNESS_INTENSITY"], 0, f(rng.uniform(0, 200))
+    if pick == 6: return R["SET_CROSSFEED"], 0, bytes([int(rng.integers(0, 2))])
+    if pick == 7: return R["SET_CROSSFEED_PRESET"], 0, bytes([int(rng.integers(0, 4))])
+    if pick == 8: return R["SET_CROSSFEED_FREQ"], 0, f(rng.uniform(300, 2500))
+    if pick == 9: return R["SET_CROSSFEED_FEED"], 0, f(rng.uniform(0, 16))
+    if pick == 10: return R["SET_CROSSFEED_ITD"], 0, bytes([int(rng.integers(0, 2))])
+    if pick == 11:
+        return R["SET_MATRIX_ROUTE"], 0, struct.pack("<BBBBf", int(rng.integers(0, 2)), int(rng.integers(0, N)), int(rng.integers(0, 2)), int(rng.integers(0, 2)),
+                                                    float(rng.uniform(-20, 4)))
+    if pick == 12: return R["SET_OUTPUT_ENABLE"], int(rng.integers(0, N)), bytes([int(rng.integers(0, 2))])
+    if pick == 13: return R["SET_OUTPUT_GAIN"], int(rng.integers(0, N)), f(rng.uniform(-30, 8))
+    if pick == 14: return R["SET_OUTPUT_MUTE"], int(rng.integers(0, N)), bytes([int(rng.integers(0, 2))])
+    if pick == 15: return R["SET_OUTPUT_DELAY"], int(rng.integers(0, N)), f(rng.choice([0.0, rng.uniform(0, 0.4), rng.uniform(0, 100)]))
+    if pick == 16: return R["SET_LEVELLER_ENABLE"], 0, bytes([int(rng.integers(0, 2))])
+    if pick == 17: return R["SET_LEVELLER_AMOUNT"], 0, f(rng.uniform(-10, 120))
+    if pick == 18: return R[str(rng.choice(["SET_LEVELLER_SPEED", "SET_LEVELLER_LOOKAHEAD"]))], 0, bytes([int(rng.integers(0, 3))])
+    if pick == 19: return R[str(rng.choice(["SET_LEVELLER_MAX_GAIN", "SET_LEVELLER_GATE"]))], 0, f(rng.uniform(-100, 30))
+    if pick == 20: return R["SET_PREAMP_CH"], int(rng.integers(0, 2)), f(rng.uniform(-20, 8))
+    return R["SET_MASTER_VOLUME"], 0, f(rng.choice([0.0, -128.0, rng.uniform(-70, 0)]))
+
+
+@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 6))))
+def test_random_request_sequences(flavor, seed):
+    """Random vendor SET requests between launches — to every stream or to one — with their side effects on audio state
+    (filter-path resets, crossfeed / leveller resets, delay changes, mutes), host volume / mute changes, and a sample-rate
+    change in the middle; compared packet by packet with one oracle per stream."""
+    from dspi_amd.host import Dspi
+    from dspi_amd import workloads as WL
+    from orclib import Oracle
+    rng = np.random.default_rng(77000 + 100 * flavor + seed)
+    fs, Bs = RATES[seed % 3]
+    S = 5
+    d = Dspi(flavor, S, device=0); o = [Oracle(flavor, detmath=True) for _ in range(S)]
+    for x in [d] + o:
+        assert x.set_rate(fs) == 0
+        x.set_volume(-12 * 256)
+        assert x.load_bulk(WL.full_chain_blob(flavor)) == 0
+    n_steps, per = 10, 5
+    B = int(rng.choice(Bs))
+    pcm = WL.synth_pcm16(S, 97 * per * n_steps, 48000, first_stream=int(rng.integers(0, 30)))
+    pos = 0
+    for k in range(n_steps):
+        for _ in range(int(rng.integers(1, 4))):
+            req, wv, payload = random_request(rng, flavor, fs)
+            target = None if rng.random() < 0.5 else int(rng.integers(0, S))
+            rc_o = [oo.vendor_set(req, wv, payload) for i, oo in enumerate(o) if target is None or i == target]
+            rc_d = d.vendor_set(req, wv, payload) if target is None else d.vendor_set(req, wv, payload, stream=target)
+            assert (rc_d == 0) == all(r == 0 for r in rc_o), f"step {k}: request {req:#x} accepted differently"
+        if rng.random() < 0.3:
+            v = int(rng.choice([0, -256 * 30, -256 * 3, 256 * 2]))
+            d.set_volume(v); [oo.set_volume(v) for oo in o]
+        if k == n_steps // 2:
+            fs, Bs = RATES[(seed + 1) % 3]
+            B = int(rng.choice(Bs))
+            assert d.set_rate(fs) == 0 and all(oo.set_rate(fs) == 0 for oo in o)
+        chunk = np.ascontiguousarray(pcm[:, pos:pos + per * B]); pos += per * B
+        pairs, sub, peaks = d.process_host(chunk, per, B)
+        for s in range(S):
+            rp, rs, rk, _ = o[s].process(chunk[s], per, B)
+            assert np.array_equal(rp, pairs[s]) and np.array_equal(rs, sub[s]) and np.array_equal(rk, peaks[s]), f"step {k} stream {s}"
+            assert o[s].status() == d.status(s), f"step {k} stream {s}: status"
+    d.close()
