@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
-    ap.add_argument("--blocks-per-step", type=int, default=25, help="packets per dspi_process call")
+    ap.add_argument("--blocks-per-step", type=int, default=50, help="packets per dspi_process call (50 ms of audio per stream at 96 kHz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out-layout", choices=["tiled", "stream"], default="tiled",
                     help="sample-word layout in HBM: the kernel's native tiles (DSPI_OUT_TILED) or stream-major S/PDIF pair buffers")
@@ -215,8 +215,9 @@ def main():
             try:
                 t = json.load(open(tpath))
                 if t.get("out_layout", "stream") == args.out_layout and t.get("hbm_bytes_per_launch"):
-                    traffic, traffic_src = t["hbm_bytes_per_launch"], os.path.basename(tpath)
-                    valu_insts = t.get("valu_insts_per_launch")
+                    scale = S * frames / float(t.get("frames_per_launch", 157286400))      # profile and run may differ in packets per launch
+                    traffic, traffic_src = t["hbm_bytes_per_launch"] * scale, os.path.basename(tpath)
+                    valu_insts = t["valu_insts_per_launch"] * scale if t.get("valu_insts_per_launch") else None
             except Exception:
                 pass
         out = {

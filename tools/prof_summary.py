@@ -6,9 +6,10 @@ usage: python tools/prof_summary.py gpurun_out/prof_<tag> profiles/<name>.md ["n
 import glob, json, os, sqlite3, sys
 
 src, dst = sys.argv[1], sys.argv[2]
+PACKETS = int(os.environ.get("PACKETS_PER_LAUNCH", 50))      # bench.py --blocks-per-step default
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 lines = [f"# rocprofv3 summary: {os.path.basename(src)}", "", note, "",
-         "Commands profiled: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (kernel trace) and `--steps 3 --warmup 1` (each PMC pass); config 3: 65 536 streams x 25 packets x 96 frames per launch = 157 286 400 frames/launch)", ""]
+         f"Commands profiled: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (kernel trace) and `--steps 3 --warmup 1` (each PMC pass); config 3: 65 536 streams x {PACKETS} packets x 96 frames per launch = {65536 * PACKETS * 96:,} frames/launch)".replace(",", " "), ""]
 tr = os.path.join(src, "trace", "trace_results.db")
 kernel_avg_us = None
 if os.path.exists(tr):
@@ -39,7 +40,7 @@ if counters:
     for n in sorted(counters):
         v, c, p = counters[n]
         lines.append(f"| {n} | {v:.6g} | {p} |")
-    frames = 157286400.0
+    frames = 65536.0 * PACKETS * 96
     d = {k: v[0] for k, v in counters.items()}
     lines += ["", "## Derived", ""]
     if "SQ_INSTS_VALU" in d:
@@ -64,6 +65,7 @@ if counters:
         if kernel_avg_us:
             lines.append(f"- at {kernel_avg_us:.0f} us/launch: {tot / kernel_avg_us / 1e6:.3f} TB/s moved, {104 * frames / kernel_avg_us / 1e6:.3f} TB/s algorithmic")
         hb["hbm_bytes_per_launch"] = tot
+        hb["frames_per_launch"] = frames
         hb["out_layout"] = os.environ.get("OUT_LAYOUT", "tiled")
         if "SQ_INSTS_VALU" in d: hb["valu_insts_per_launch"] = d["SQ_INSTS_VALU"]
         json.dump(hb, open(os.path.join(os.path.dirname(dst), "traffic_" + os.path.basename(dst).split("_")[0] + ".json"), "w"))
