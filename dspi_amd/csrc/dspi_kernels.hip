@@ -779,6 +779,7 @@ struct MasterQ28 {
     int32_t env_l, env_r;
     float gsm_db;
     int32_t g_cur, g_prev;
+    int32_t g_last;          // hand-off: the gain the previous packet's ramp ended on
     uint32_t rp1, rp2;
     // pass-2 gain ramp: gain_i = g_prev + trunc((g_cur - g_prev) * i / (B-1)) (leveller.c:352) kept exact without 64-bit
     // division: (g_cur-g_prev) = D*(B-1) + R  ->  gain_i = g_prev + D*i + trunc(R*i/(B-1)), the last term carried incrementally
@@ -787,106 +788,106 @@ struct MasterQ28 {
     uint32_t clip;
 };
 
+// The Q28 master side is split over two waves so that no wave carries 24 band visits per chunk while another carries 10:
+//   role 0: pass 1 of the LEFT channel (conversion, loudness, master EQ, envelope -> ring) + the hand-off of both channels
+//           (ring -> leveller pass 2, peaks, crossfeed -> LDS), `lag` steps later;
+//   role 3: pass 1 of the RIGHT channel + the fifth output.
+// Every sample travels through the ring (also with the leveller off: it is the only path from role 3 to role 0).  Role 3
+// posts its envelope in LDS when a packet ends; role 0 takes the gain decision (leveller.c:304-334) at the start of the
+// next step from its own end-of-packet envelope and the posted one, and queues it for the hand-off of that packet.
+// Visibility of the right-channel rows: role 3 drains its stores in the middle of the NEXT step (before that step's ring
+// stores), lag >= 2, and role 0 reads them with agent-scope loads (past the CU's vector L1).
 // IMG = ImgPtr: the workgroup's image, scalar loads (PL false).  IMG = const DevImage *: per-lane images (PL true), for rows
-// whose streams carry different presets — then every lane's samples go through the ring (see master_step_f32).
-template <bool TAIL, bool PL, class IMG>
-__device__ __forceinline__ void master_step_q28(const KArgs &a, IMG img, const StateMap &sm, const Geo &g, MasterQ28 &m,
-                                                int32_t *__restrict__ lds_state, int32_t *__restrict__ xch_base, uint32_t wg, uint32_t lane, uint32_t stream,
-                                                bool do_p1, uint32_t k1, uint32_t c1, bool do_item, uint32_t kq, uint32_t cq, uint32_t q) {
+// whose streams carry different presets.
+constexpr int kQ28Mail = 4;      // queued gain decisions (packets between decision and hand-off: at most 2)
+
+template <bool TAIL, int CH, class IMG>
+__device__ __forceinline__ void master_p1_q28(const KArgs &a, IMG img, const StateMap &sm, const Geo &g, int32_t &env, uint32_t &rp1,
+                                              int32_t *__restrict__ lds_state, uint32_t wg, uint32_t lane, uint32_t stream, uint32_t k1, uint32_t c1) {
+    constexpr uint32_t ROW = make_state_map(0).row;
+    const uint32_t flags = img->flags;
+    const bool lev_on = flags & IF_LEVELLER_ON;
+    const int32_t unity = 1 << 28;
+    int32_t x[T];
+    uint32_t *plane = a.ring + ((size_t)wg * 2 + CH) * kRingLen * ROW + lane;
+    const int n = TAIL ? (int)min((uint32_t)T, g.B - c1 * T) : T;
+    // ---- PASS 1: input conversion + preamp (usb_audio.c:997-1015) ----
+    const size_t frame0 = ((size_t)stream * g.n_blocks + k1) * g.B + (size_t)c1 * T;
+    const int32_t pre = img->preamp[CH].i;
+    if (a.bit_depth == 24) {
+        const uint16_t *p = reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(a.pcm) + frame0 * 6);
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (TAIL && i >= n) break;
+            int32_t v;
+            if (CH == 0) { uint32_t w0 = p[i * 3], w1 = p[i * 3 + 1]; v = (int32_t)((w0 | (w1 << 16)) << 8) >> 2; }     // 24-bit left-justified, then >>2: net <<6
+            else { uint32_t w1 = p[i * 3 + 1], w2 = p[i * 3 + 2]; v = (int32_t)(((w1 >> 8) | (w2 << 8)) << 8) >> 2; }
+            x[i] = qmul(v, pre);
+        }
+    } else {
+        const uint32_t *p = static_cast<const uint32_t *>(a.pcm) + frame0;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            if (TAIL && i >= n) break;
+            const uint32_t w = p[i];
+            const int32_t v = CH == 0 ? (int32_t)((uint32_t)(int32_t)(int16_t)(w & 0xffffu) << 14) : (int32_t)((uint32_t)((int32_t)w >> 16) << 14);
+            x[i] = qmul(v, pre);
+        }
+    }
+    // ---- loudness (usb_audio.c:1017-1047) and master EQ (:1049-1055) ----
+    run_bands_q28<TAIL, 2>(x, n, &img->loud[0], lds_state + (sm.loud + 4 * CH) * kLanes + lane);
+    if (!(flags & IF_BYPASS_MASTER_EQ) && !(img->ch_bypassed & (1u << CH)))
+        run_bands_q28<TAIL, kBands>(x, n, &img->eq[CH][0], lds_state + (sm.eq + CH * kBands * 2) * kLanes + lane);
+    // ---- leveller pass 1 (leveller.c:282-302): envelope, samples parked in the ring ----
+    const int32_t aq = img->lv_alpha_rms_q28, naq = unity - aq;
+    const uint32_t base = (rp1 + c1 * T) & (kRingLen - 1);
+    const bool flat = __all(base + T <= (uint32_t)kRingLen);
+    uint32_t *wl = plane + (size_t)base * ROW;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous step's rows are complete before this step's barrier
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        if (TAIL && i >= n) break;
+        if (lev_on) {
+            const int32_t sq = qmul(x[i], x[i]);
+            env = wadd(qmul(aq, env), qmul(naq, sq));
+        }
+        if (flat) wl[i * ROW] = (uint32_t)x[i];
+        else plane[(size_t)((base + i) & (kRingLen - 1)) * ROW] = (uint32_t)x[i];
+    }
+    if (c1 == g.cpb - 1) rp1 = (rp1 + g.B) & (kRingLen - 1);
+}
+
+// hand-off of chunk (kq, cq): both channels from the ring, pass 2, peaks, crossfeed -> LDS
+template <bool TAIL, class IMG>
+__device__ __forceinline__ void master_item_q28(const KArgs &a, IMG img, const StateMap &sm, const Geo &g, MasterQ28 &m, const int32_t *__restrict__ mail,
+                                                int32_t *__restrict__ xch_base, uint32_t wg, uint32_t lane, uint32_t stream, uint32_t kq, uint32_t cq, uint32_t q) {
     constexpr uint32_t ROW = make_state_map(0).row;
     const uint32_t col = lane;
     const uint32_t flags = img->flags;
     const bool lev_on = flags & IF_LEVELLER_ON;
-    const bool ringflow = PL || lev_on;      // samples travel through the ring (always, with per-lane images)
     int32_t xl[T], xr[T];
-    uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * ROW + col;
+    const uint32_t *ring = a.ring + (size_t)wg * kRingLen * 2 * ROW + col;
     const int nq = TAIL ? (int)min((uint32_t)T, g.B - cq * T) : T;
     const int32_t unity = 1 << 28;
-
-    int32_t ol[T], orr[T];
-    if (ringflow && do_item) {
-        if (lev_on && cq == 0) {
-            const int32_t d = wsub(m.g_cur, m.g_prev);
-            if (g.B == 1) { m.p2_base = m.g_cur; m.p2_D = 0; m.p2_R = 0; }
-            else { const int32_t mm = (int32_t)g.B - 1; m.p2_base = m.g_prev; m.p2_D = d / mm; m.p2_R = d % mm; }
-            m.p2_acc = 0; m.p2_carry = 0;
-        }
+    if (lev_on && cq == 0) {
+        const int32_t g_new = mail[(kq & (kQ28Mail - 1)) * kLanes + lane];       // decided when pass 1 of packet kq ended
+        const int32_t d = wsub(g_new, m.g_last);
+        if (g.B == 1) { m.p2_base = g_new; m.p2_D = 0; m.p2_R = 0; }
+        else { const int32_t mm = (int32_t)g.B - 1; m.p2_base = m.g_last; m.p2_D = d / mm; m.p2_R = d % mm; }
+        m.p2_acc = 0; m.p2_carry = 0;
+        m.g_last = g_new;
+    }
+    {
         const uint32_t back = (lev_on && (flags & IF_LOOKAHEAD)) ? (uint32_t)kLookahead : 0u;
         const uint32_t base = (m.rp2 + cq * T - back) & (kRingLen - 1);
-        const bool flat = __all(base + T <= (uint32_t)kRingLen);
-        const uint32_t *rl = ring + (size_t)base * ROW;
 #pragma unroll
         for (int i = 0; i < T; ++i) {
             if (TAIL && i >= nq) break;
-            if (flat) { ol[i] = (int32_t)rl[i * ROW]; orr[i] = (int32_t)rl[(kRingLen + i) * ROW]; }
-            else { uint32_t pos = (base + i) & (kRingLen - 1); ol[i] = (int32_t)ring[(size_t)pos * ROW]; orr[i] = (int32_t)ring[(size_t)(kRingLen + pos) * ROW]; }
+            const uint32_t pos = (base + i) & (kRingLen - 1);
+            xl[i] = (int32_t)ring[(size_t)pos * ROW];
+            xr[i] = (int32_t)__hip_atomic_load(ring + (size_t)(kRingLen + pos) * ROW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written by role 3
         }
     }
-
-    if (do_p1) {
-        const int n = TAIL ? (int)min((uint32_t)T, g.B - c1 * T) : T;
-        // ---- PASS 1: input conversion + preamp (usb_audio.c:997-1015) ----
-        const size_t frame0 = ((size_t)stream * g.n_blocks + k1) * g.B + (size_t)c1 * T;
-        const int32_t pl = img->preamp[0].i, pr = img->preamp[1].i;
-        if (a.bit_depth == 24) {
-            const uint16_t *p = reinterpret_cast<const uint16_t *>(static_cast<const uint8_t *>(a.pcm) + frame0 * 6);
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                if (TAIL && i >= n) break;
-                uint32_t w0 = p[i * 3], w1 = p[i * 3 + 1], w2 = p[i * 3 + 2];
-                int32_t l = (int32_t)((w0 | (w1 << 16)) << 8) >> 2;          // 24-bit left-justified, then >>2: net <<6
-                int32_t r = (int32_t)(((w1 >> 8) | (w2 << 8)) << 8) >> 2;
-                xl[i] = qmul(l, pl);
-                xr[i] = qmul(r, pr);
-            }
-        } else {
-            const uint32_t *p = static_cast<const uint32_t *>(a.pcm) + frame0;
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                if (TAIL && i >= n) break;
-                const uint32_t w = p[i];
-                xl[i] = qmul((int32_t)((uint32_t)(int32_t)(int16_t)(w & 0xffffu) << 14), pl);
-                xr[i] = qmul((int32_t)((uint32_t)((int32_t)w >> 16) << 14), pr);
-            }
-        }
-        // ---- loudness (usb_audio.c:1017-1047) and master EQ (:1049-1055) ----
-        run_bands_q28<TAIL, 2>(xl, n, &img->loud[0], lds_state + (sm.loud + 0) * kLanes + lane);
-        run_bands_q28<TAIL, 2>(xr, n, &img->loud[0], lds_state + (sm.loud + 4) * kLanes + lane);
-        if (!(flags & IF_BYPASS_MASTER_EQ)) {
-            if (!(img->ch_bypassed & 1u)) run_bands_q28<TAIL, kBands>(xl, n, &img->eq[0][0], lds_state + (sm.eq + 0) * kLanes + lane);
-            if (!(img->ch_bypassed & 2u)) run_bands_q28<TAIL, kBands>(xr, n, &img->eq[1][0], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
-        }
-        if (ringflow) {
-            // ---- leveller pass 1 (leveller.c:282-302) ----
-            const int32_t aq = img->lv_alpha_rms_q28, naq = unity - aq;
-            const uint32_t base = (m.rp1 + c1 * T) & (kRingLen - 1);
-            const bool flat = __all(base + T <= (uint32_t)kRingLen);
-            uint32_t *wl = ring + (size_t)base * ROW;
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-                if (TAIL && i >= n) break;
-                if (lev_on) {
-                    const int32_t ql = qmul(xl[i], xl[i]), qr = qmul(xr[i], xr[i]);
-                    m.env_l = wadd(qmul(aq, m.env_l), qmul(naq, ql));
-                    m.env_r = wadd(qmul(aq, m.env_r), qmul(naq, qr));
-                }
-                if (flat) { wl[i * ROW] = (uint32_t)xl[i]; wl[(kRingLen + i) * ROW] = (uint32_t)xr[i]; }
-                else { uint32_t pos = (base + i) & (kRingLen - 1); ring[(size_t)pos * ROW] = (uint32_t)xl[i]; ring[(size_t)(kRingLen + pos) * ROW] = (uint32_t)xr[i]; }
-            }
-            if (c1 == g.cpb - 1) {   // leveller.c:304-334
-                if (lev_on) {
-                    const float inv = 1.0f / (float)(1 << 28);
-                    const float el = (float)m.env_l * inv, er = (float)m.env_r * inv;
-                    const float gl = leveller_block_gain(img, m.gsm_db, el > er ? el : er, g.B);
-                    m.g_prev = m.g_cur;
-                    m.g_cur = f2i_sat(gl * (float)(1 << 28));
-                }
-                m.rp1 = (m.rp1 + g.B) & (kRingLen - 1);
-            }
-        }
-    }
-
-    if (!do_item) return;
     if (lev_on) {
         // ---- leveller pass 2 (leveller.c:336-386) ----
         const float inv = 1.0f / (float)(1 << 28);
@@ -896,7 +897,7 @@ __device__ __forceinline__ void master_step_q28(const KArgs &a, IMG img, const S
             if (TAIL && i >= nq) break;
             int32_t gain = wadd(m.p2_base, m.p2_carry);
             if (gain > unity) {
-                float peak = fabsf((float)ol[i] * inv), prk = fabsf((float)orr[i] * inv);
+                float peak = fabsf((float)xl[i] * inv), prk = fabsf((float)xr[i] * inv);
                 if (prk > peak) peak = prk;
                 if (peak > 0.0f) {
                     const float mgf = 0.70795f / peak;
@@ -904,19 +905,16 @@ __device__ __forceinline__ void master_step_q28(const KArgs &a, IMG img, const S
                     if (mgq < gain) gain = (mgq > unity) ? mgq : unity;
                 }
             }
-            xl[i] = qmul(ol[i], gain);
-            xr[i] = qmul(orr[i], gain);
+            xl[i] = qmul(xl[i], gain);
+            xr[i] = qmul(xr[i], gain);
             // advance the ramp to sample i+1
             m.p2_base = wadd(m.p2_base, m.p2_D);
             m.p2_acc += m.p2_R;
             if (m.p2_acc >= mm && mm > 0) { m.p2_acc -= mm; m.p2_carry += 1; }
             else if (m.p2_acc <= -mm && mm > 0) { m.p2_acc += mm; m.p2_carry -= 1; }
         }
-    } else if (ringflow) {      // per-lane images, leveller bypassed on this lane: the samples pass through
-#pragma unroll
-        for (int i = 0; i < T; ++i) { if (TAIL && i >= nq) break; xl[i] = ol[i]; xr[i] = orr[i]; }
     }
-    if (ringflow && cq == g.cpb - 1) m.rp2 = (m.rp2 + g.B) & (kRingLen - 1);
+    if (cq == g.cpb - 1) m.rp2 = (m.rp2 + g.B) & (kRingLen - 1);
     // ---- PASS 3: master peaks + crossfeed (usb_audio.c:1065-1073, crossfeed.c:161-180) ----
     if (cq == 0) { m.pk_l = 0; m.pk_r = 0; }
     const bool xf = flags & IF_CROSSFEED_ON;
@@ -1164,36 +1162,60 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     g.cpb = (g.B + T - 1) / T;
     g.items = g.n_blocks * g.cpb;
     // float (per-lane images): the schedule cannot depend on one lane's flags, every lane goes through the ring
-    g.lag = (FLAVOR || PL) ? g.cpb : ((img->flags & IF_LEVELLER_ON) ? g.cpb : 0u);
+    // Q28: every sample goes through the ring too (the two master waves meet there), never sooner than two steps
+    g.lag = FLAVOR ? g.cpb : (g.cpb > 2u ? g.cpb : 2u);
     g.steps = g.items + g.lag + 1;
 
+    int32_t *q_mail = reinterpret_cast<int32_t *>(xch) + 2 * 2 * T * kLanes;      // [kQ28Mail][64] queued gain decisions (role 0)
+    int32_t *q_envr = q_mail + kQ28Mail * kLanes;                                 // [2][64] right envelope at packet end (role 3 -> role 0)
     if (wave == 0 && FLAVOR == 0) {
+        // ---- role 0: pass 1 of the left channel + hand-off of both ----
         int32_t *qstate = reinterpret_cast<int32_t *>(lds);
         int32_t *qxch = reinterpret_cast<int32_t *>(xch);
         MasterQ28 m;
         m.lpL = (int32_t)gs[(sm.xfeed + 0) * ROW]; m.lpR = (int32_t)gs[(sm.xfeed + 1) * ROW];
         m.apL = (int32_t)gs[(sm.xfeed + 2) * ROW]; m.apR = (int32_t)gs[(sm.xfeed + 3) * ROW];
-        m.env_l = (int32_t)gs[(sm.lev + 0) * ROW]; m.env_r = (int32_t)gs[(sm.lev + 1) * ROW];
+        m.env_l = (int32_t)gs[(sm.lev + 0) * ROW]; m.env_r = 0;
         m.gsm_db = as_f(gs[(sm.lev + 2) * ROW]); m.g_cur = (int32_t)gs[(sm.lev + 3) * ROW]; m.g_prev = (int32_t)gs[(sm.lev + 4) * ROW];
+        m.g_last = m.g_cur;
         m.rp1 = m.rp2 = gs[sm.ring_pos * ROW] & (kRingLen - 1);
         m.p2_base = 1 << 28; m.p2_D = m.p2_R = m.p2_acc = m.p2_carry = 0; m.pk_l = m.pk_r = 0;
         m.clip = gs[(sm.clip + 0) * ROW];
         uint32_t k1 = 0, c1 = 0, kq = 0, cq = 0;
+        int32_t env_end = 0;
+        bool decide = false;
+        uint32_t kd = 0;
         for (uint32_t st = 0; st < g.steps; ++st) {
+            if (decide) {      // gain decision of packet kd (leveller.c:304-334): pass 1 of both channels ended in the previous step
+                const bool lev_on = (PL ? img_l->flags : img->flags) & IF_LEVELLER_ON;
+                if (lev_on) {
+                    const float inv = 1.0f / (float)(1 << 28);
+                    const float el = (float)env_end * inv, er = (float)q_envr[(kd & 1u) * kLanes + lane] * inv;
+                    const float gl = PL ? leveller_block_gain(img_l, m.gsm_db, el > er ? el : er, g.B) : leveller_block_gain(img, m.gsm_db, el > er ? el : er, g.B);
+                    m.g_prev = m.g_cur;
+                    m.g_cur = f2i_sat(gl * (float)(1 << 28));
+                }
+                q_mail[(kd & (kQ28Mail - 1)) * kLanes + lane] = m.g_cur;
+                decide = false;
+            }
             const bool do_p1 = st < g.items;
             const bool do_item = st >= g.lag && st < g.items + g.lag;
             const uint32_t q = st - g.lag;
-            if (do_p1 || do_item) {
-                if (PL) master_step_q28<TAIL, true>(a, img_l, sm, g, m, qstate, qxch, wg, lane, stream, do_p1, k1, c1, do_item, kq, cq, q);
-                else master_step_q28<TAIL, false>(a, img, sm, g, m, qstate, qxch, wg, lane, stream, do_p1, k1, c1, do_item, kq, cq, q);
+            if (do_p1) {
+                if (PL) master_p1_q28<TAIL, 0>(a, img_l, sm, g, m.env_l, m.rp1, qstate, wg, lane, stream, k1, c1);
+                else master_p1_q28<TAIL, 0>(a, img, sm, g, m.env_l, m.rp1, qstate, wg, lane, stream, k1, c1);
+                if (++c1 == g.cpb) { env_end = m.env_l; decide = true; kd = k1; c1 = 0; ++k1; }
             }
-            if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
-            if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
+            if (do_item) {
+                if (PL) master_item_q28<TAIL>(a, img_l, sm, g, m, q_mail, qxch, wg, lane, stream, kq, cq, q);
+                else master_item_q28<TAIL>(a, img, sm, g, m, q_mail, qxch, wg, lane, stream, kq, cq, q);
+                if (++cq == g.cpb) { cq = 0; ++kq; }
+            }
             lds_barrier();
         }
         gs[(sm.xfeed + 0) * ROW] = (uint32_t)m.lpL; gs[(sm.xfeed + 1) * ROW] = (uint32_t)m.lpR;
         gs[(sm.xfeed + 2) * ROW] = (uint32_t)m.apL; gs[(sm.xfeed + 3) * ROW] = (uint32_t)m.apR;
-        gs[(sm.lev + 0) * ROW] = (uint32_t)m.env_l; gs[(sm.lev + 1) * ROW] = (uint32_t)m.env_r;
+        gs[(sm.lev + 0) * ROW] = (uint32_t)m.env_l;
         gs[(sm.lev + 2) * ROW] = as_u(m.gsm_db); gs[(sm.lev + 3) * ROW] = (uint32_t)m.g_cur; gs[(sm.lev + 4) * ROW] = (uint32_t)m.g_prev;
         gs[sm.ring_pos * ROW] = m.rp1;
         gs[(sm.clip + 0) * ROW] = m.clip;
@@ -1201,16 +1223,24 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         int32_t *qstate = reinterpret_cast<int32_t *>(lds);
         int32_t *qpk = reinterpret_cast<int32_t *>(lds_pk);
         const int32_t *qxch = reinterpret_cast<const int32_t *>(xch);
-        // 5 outputs over waves 1..3: pair 0, pair 1, sub
+        // 5 outputs over waves 1..3: pair 0, pair 1, sub; wave 3 also runs pass 1 of the right channel (role 3 above)
         const int o_first = (wave - 1) * 2;
         const int o_count = (wave <= sm.n_pairs) ? 2 : 1;
+        const bool right = (wave == 3);
         OutQ28 s;
         s.widx = gs[sm.widx * ROW];
         s.loading = gs[(sm.mute + 0) * ROW]; s.counter = gs[(sm.mute + 1) * ROW]; s.smooth = as_f(gs[(sm.mute + 2) * ROW]);
         s.vmm = 0;
         s.clip = gs[(sm.clip + wave) * ROW];
-        uint32_t kq = 0, cq = 0;
+        int32_t env_r = right ? (int32_t)gs[(sm.lev + 1) * ROW] : 0;
+        uint32_t rp1 = gs[sm.ring_pos * ROW] & (kRingLen - 1);
+        uint32_t kq = 0, cq = 0, k1 = 0, c1 = 0;
         for (uint32_t st = 0; st < g.steps; ++st) {
+            if (right && st < g.items) {
+                if (PL) master_p1_q28<TAIL, 1>(a, img_l, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
+                else master_p1_q28<TAIL, 1>(a, img, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
+                if (++c1 == g.cpb) { q_envr[(k1 & 1u) * kLanes + lane] = env_r; c1 = 0; ++k1; }
+            }
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
                 if (PL) output_item_q28<TAIL>(a, img_l, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
@@ -1223,6 +1253,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             gs[sm.widx * ROW] = s.widx;
             gs[(sm.mute + 0) * ROW] = s.loading; gs[(sm.mute + 1) * ROW] = s.counter; gs[(sm.mute + 2) * ROW] = as_u(s.smooth);
         }
+        if (right) gs[(sm.lev + 1) * ROW] = (uint32_t)env_r;
         gs[(sm.clip + wave) * ROW] = s.clip;
     } else if (wave == 0) {
         MasterF32 m;
@@ -1363,7 +1394,8 @@ __global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
 // ------------------------------------------------------------------------------------------
 size_t chain_lds_bytes(int flavor, int packed) {
     const StateMap sm = make_state_map(flavor);
-    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox : 0)) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);
+    // Q28 one-stream kernel: + queued gain decisions and the posted right-channel envelope (kQ28Mail + 2 rows)
+    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox : (flavor ? 0 : 6))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);
 }
 
 template <int FLAVOR, bool PL>

@@ -306,35 +306,37 @@ def test_full_size_properties():
     d.close()
 
 
-@pytest.mark.parametrize("fs,B", [(96000, 96), (44100, 45)])
-def test_full_size_all_tiles_agree(fs, B):
-    """Race detector at full size on the path the bench times (tiled words, device buffers, several launches): all 512
-    tiles get the same 128 streams of input, so every tile must produce the words of tile 0 — which is checked against
-    the oracle on a few streams.  A stale ring row, a lost barrier or a role mix-up in any workgroup shows up here."""
+@pytest.mark.parametrize("flavor,fs,B", [(1, 96000, 96), (1, 44100, 45), (1, 48000, 16), (0, 48000, 48), (0, 44100, 44), (0, 48000, 16), (0, 48000, 20), (0, 48000, 7)])
+def test_full_size_all_tiles_agree(flavor, fs, B):
+    """Race detector at full size on the path the bench times (tiled words, device buffers, several launches): every
+    tile gets the same streams of input, so every tile must produce the words of tile 0 — which is checked against the
+    oracle on a few streams.  A stale ring row, a lost barrier or a role mix-up in any workgroup shows up here (float:
+    512 workgroups of twelve waves; Q28: 1024 workgroups whose two master waves meet in the ring)."""
     import torch
-    blocks, S, calls = 14, 65536, 3
-    d = Dspi(1, S, device=0)
-    d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(WL.full_chain_blob(1)) == 0
+    blocks, S, calls = (14 if B > 20 else 60), 65536, 3
+    n_out, n_ch = (9, 11) if flavor else (5, 7)
+    d = Dspi(flavor, S, device=0)
+    d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(WL.full_chain_blob(flavor)) == 0
     R = d.tile_streams()
     base = WL.synth_pcm16(R, B * blocks * calls, fs)
     dev = torch.device("cuda", 0)
     tiles = S // R
     frames = B * blocks
-    pairs = torch.empty((tiles, 8, frames, R), dtype=torch.int32, device=dev); sub = torch.empty((tiles, frames, R), dtype=torch.int32, device=dev)
-    peaks = torch.empty((S, blocks, 11), dtype=torch.int16, device=dev)
+    pairs = torch.empty((tiles, n_out - 1, frames, R), dtype=torch.int32, device=dev); sub = torch.empty((tiles, frames, R), dtype=torch.int32, device=dev)
+    peaks = torch.empty((S, blocks, n_ch), dtype=torch.int16, device=dev)
     for c in range(calls):
         part = torch.from_numpy(np.ascontiguousarray(base[:, c * frames:(c + 1) * frames])).to(dev)
         pcm = part.repeat(tiles, 1, 1).contiguous()
         d.process_device(pcm.data_ptr(), blocks, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=True); d.sync()
         assert bool((pairs == pairs[0:1]).all()), f"launch {c}: a tile's pair words differ from tile 0"
         assert bool((sub == sub[0:1]).all()), f"launch {c}: a tile's sub words differ from tile 0"
-        pk = peaks.view(tiles, R, blocks, 11)
+        pk = peaks.view(tiles, R, blocks, n_ch)
         assert bool((pk == pk[0:1]).all()), f"launch {c}: a tile's peaks differ from tile 0"
     p0 = pairs[0].cpu().numpy(); s0 = sub[0].cpu().numpy()
-    for s in (0, 1, 64, 127):
-        (rp, rs, _, _), _ = oracle_run(1, fs, -20 * 256, WL.full_chain_blob(1), base[s], blocks * calls, B, 16)
+    for s in (0, 1, R // 2, R - 1):
+        (rp, rs, _, _), _ = oracle_run(flavor, fs, -20 * 256, WL.full_chain_blob(flavor), base[s], blocks * calls, B, 16)
         last = rp[:, (calls - 1) * frames:, :]                      # [pair][frame][side] of the last launch
-        got = np.stack([np.stack([p0[2 * p, :, s], p0[2 * p + 1, :, s]], axis=-1) for p in range(4)])
+        got = np.stack([np.stack([p0[2 * p, :, s], p0[2 * p + 1, :, s]], axis=-1) for p in range((n_out - 1) // 2)])
         assert np.array_equal(last, got) and np.array_equal(rs[(calls - 1) * frames:], s0[:, s])
     d.close()
 
