@@ -1202,13 +1202,26 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             const bool do_item = st >= g.lag && st < g.items + g.lag;
             const uint32_t q = st - g.lag;
             if (do_p1) {
-                if (PL) master_p1_q28<TAIL, 0>(a, img_l, sm, g, m.env_l, m.rp1, qstate, wg, lane, stream, k1, c1);
-                else master_p1_q28<TAIL, 0>(a, img, sm, g, m.env_l, m.rp1, qstate, wg, lane, stream, k1, c1);
+                // kernels for ragged packets: full chunks still take the exit-free instantiation (the sample arrays are local
+                // to these functions, so the two variants meet in scalars only)
+                const bool ragged = TAIL && (c1 + 1) * T > g.B;
+                if (ragged) {
+                    if (PL) master_p1_q28<true, 0>(a, img_l, sm, g, m.env_l, m.rp1, qstate, wg, lane, stream, k1, c1);
+                    else master_p1_q28<true, 0>(a, img, sm, g, m.env_l, m.rp1, qstate, wg, lane, stream, k1, c1);
+                } else {
+                    if (PL) master_p1_q28<false, 0>(a, img_l, sm, g, m.env_l, m.rp1, qstate, wg, lane, stream, k1, c1);
+                    else master_p1_q28<false, 0>(a, img, sm, g, m.env_l, m.rp1, qstate, wg, lane, stream, k1, c1);
+                }
                 if (++c1 == g.cpb) { env_end = m.env_l; decide = true; kd = k1; c1 = 0; ++k1; }
             }
             if (do_item) {
-                if (PL) master_item_q28<TAIL>(a, img_l, sm, g, m, q_mail, qxch, wg, lane, stream, kq, cq, q);
-                else master_item_q28<TAIL>(a, img, sm, g, m, q_mail, qxch, wg, lane, stream, kq, cq, q);
+                if (TAIL && (cq + 1) * T > g.B) {
+                    if (PL) master_item_q28<true>(a, img_l, sm, g, m, q_mail, qxch, wg, lane, stream, kq, cq, q);
+                    else master_item_q28<true>(a, img, sm, g, m, q_mail, qxch, wg, lane, stream, kq, cq, q);
+                } else {
+                    if (PL) master_item_q28<false>(a, img_l, sm, g, m, q_mail, qxch, wg, lane, stream, kq, cq, q);
+                    else master_item_q28<false>(a, img, sm, g, m, q_mail, qxch, wg, lane, stream, kq, cq, q);
+                }
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
             lds_barrier();
@@ -1237,14 +1250,24 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         uint32_t kq = 0, cq = 0, k1 = 0, c1 = 0;
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (right && st < g.items) {
-                if (PL) master_p1_q28<TAIL, 1>(a, img_l, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
-                else master_p1_q28<TAIL, 1>(a, img, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
+                if (TAIL && (c1 + 1) * T > g.B) {
+                    if (PL) master_p1_q28<true, 1>(a, img_l, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
+                    else master_p1_q28<true, 1>(a, img, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
+                } else {
+                    if (PL) master_p1_q28<false, 1>(a, img_l, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
+                    else master_p1_q28<false, 1>(a, img, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
+                }
                 if (++c1 == g.cpb) { q_envr[(k1 & 1u) * kLanes + lane] = env_r; c1 = 0; ++k1; }
             }
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
-                if (PL) output_item_q28<TAIL>(a, img_l, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
-                else output_item_q28<TAIL>(a, img, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
+                if (TAIL && (cq + 1) * T > g.B) {
+                    if (PL) output_item_q28<true>(a, img_l, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
+                    else output_item_q28<true>(a, img, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
+                } else {
+                    if (PL) output_item_q28<false>(a, img_l, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
+                    else output_item_q28<false>(a, img, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
+                }
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
             lds_barrier();
@@ -1274,7 +1297,12 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             const bool do_item = st >= g.lag && st < g.items + g.lag;
             const uint32_t q = st - g.lag;
             if (do_p1 || do_item) {
-                master_step_f32<TAIL>(a, img_l, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
+                // (ragged packets: full chunks take the exit-free instantiation; lag is a whole packet, so both halves of a
+                // step sit at the same chunk of their packets)
+                if (TAIL && ((do_p1 ? c1 : cq) + 1) * T > g.B)
+                    master_step_f32<true>(a, img_l, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
+                else
+                    master_step_f32<false>(a, img_l, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
             }
             if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
             if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
@@ -1308,7 +1336,10 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
-                output_item_f32<TAIL>(a, img_l, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
+                if (TAIL && (cq + 1) * T > g.B)
+                    output_item_f32<true>(a, img_l, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
+                else
+                    output_item_f32<false>(a, img_l, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
             WT_BEFORE_BARRIER;

@@ -7,7 +7,8 @@ import torch
 from dspi_amd import wire as W, workloads as WL
 from dspi_amd.host import Dspi
 
-S, NB, B, FS = int(os.environ.get("S", 16384)), 25, 96, 96000
+S, NB = int(os.environ.get("S", 16384)), 25
+B, FS = int(os.environ.get("B", 96)), int(os.environ.get("FS", 96000))      # e.g. B=45 FS=44100 for ragged packets
 dev = torch.device("cuda", 0)
 d = Dspi(1, S, device=0); d.set_rate(FS); d.set_volume(-20 * 256)
 assert d.load_bulk(WL.full_chain_blob(1)) == 0
