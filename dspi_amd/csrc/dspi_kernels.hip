@@ -350,13 +350,17 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, const DevImage *
                     }
                 }
                 // fetch the next chunk now; it lands while this one goes through loudness + EQ
-                const bool more = (c1 + 1 < g.cpb) || (k1 + 1 < g.n_blocks);
+                // (only a FULL next chunk: in a kernel for ragged packets the short chunk is read by the guarded variant, and
+                // 16 frames from its start may run past the stream's buffer)
+                const uint32_t nc = (c1 + 1 < g.cpb) ? c1 + 1 : 0u;
+                const bool more = ((c1 + 1 < g.cpb) || (k1 + 1 < g.n_blocks)) && (nc + 1) * T <= g.B;
                 m.pre_valid = more;
                 if (more && active) {
 #pragma unroll
                     for (int v = 0; v < T / 4; ++v) m.pre[v] = ld4(p + T + v * 4);   // chunks of one stream are contiguous across packets
                 }
             } else {
+                m.pre_valid = 0;
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
                     if (i >= n) break;
@@ -652,12 +656,14 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, const DevImage *
                 }
             }
         } else {
+            // a pair whose two outputs are both disabled is zero-filled whatever its delay lines still hold (usb_audio.c:930-933)
+            const bool pair_dead = !(((img->out_enabled >> o) | (img->out_enabled >> (o ^ 1))) & 1u);
             int32_t wv[T];
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
                 float d = fmaxf(-1.0f, fminf(1.0f, x[i]));
-                wv[i] = (int32_t)(d * 8388607.0f);
+                wv[i] = pair_dead ? 0 : (int32_t)(d * 8388607.0f);
             }
             const int pair = o >> 1, side = o & 1;
             const bool partner_here = side ? (j >= 1) : (j + 1 < o_count && o + 1 < N - 1);
@@ -1087,12 +1093,15 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const S
                 for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[i] = live ? x[i] : 0; }
             }
         } else {
+            // a pair whose two outputs are both disabled is zero-filled whatever its delay lines still hold (usb_audio.c:1247-1250)
+            const bool pair_dead = !(((img->out_enabled >> o) | (img->out_enabled >> (o ^ 1))) & 1u);
             int32_t wv[T];
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
                 int32_t v = wadd(x[i], 1 << 5) >> 6;                                      // (x + 32) >> 6
-                wv[i] = v > 0x7FFFFF ? 0x7FFFFF : (v < -0x800000 ? -0x800000 : v);       // clip_s24
+                v = v > 0x7FFFFF ? 0x7FFFFF : (v < -0x800000 ? -0x800000 : v);            // clip_s24
+                wv[i] = pair_dead ? 0 : v;
             }
             const int pair = o >> 1, side = o & 1;
             const bool partner_here = side ? (j >= 1) : (j + 1 < o_count && o + 1 < N - 1);

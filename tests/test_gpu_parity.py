@@ -120,7 +120,7 @@ def test_vendor_requests_between_launches(flavor):
     fs, B = 48000, 48
     S = 4
     d = Dspi(flavor, S, device=0); o = [Oracle(flavor, detmath=True) for _ in range(S)]
-    pcm = WL.synth_pcm16(S, B * 60, fs)
+    pcm = WL.synth_pcm16(S, B * 72, fs)
     R = W.REQ
     f = lambda v: struct.pack("<f", v)
     steps = [
@@ -134,6 +134,10 @@ def test_vendor_requests_between_launches(flavor):
         lambda x: x.factory_defaults(),
         lambda x: x.vendor_set(R["SET_MASTER_VOLUME"], 0, f(-3.0)),
         lambda x: x.load_slot(slot_image),
+        # both outputs of pair 1 switched off while their delay lines still hold audio: the pair is zero-filled at once
+        # (usb_audio.c:930-933), the meters still see the tail
+        lambda x: (x.vendor_set(R["SET_OUTPUT_ENABLE"], 2, b"\x00"), x.vendor_set(R["SET_OUTPUT_ENABLE"], 3, b"\x00")),
+        lambda x: x.vendor_set(R["SET_OUTPUT_ENABLE"], 3, b"\x01"),
     ]
     ref = Oracle(flavor); ref.load_bulk(WL.full_chain_blob(flavor)); slot_image = ref.save_slot(0)
     for k, step in enumerate(steps):
