@@ -144,6 +144,17 @@ def test_random_request_sequences(flavor, seed):
         if rng.random() < 0.3:
             v = int(rng.choice([0, -256 * 30, -256 * 3, 256 * 2]))
             d.set_volume(v); [oo.set_volume(v) for oo in o]
+        big = rng.random()
+        if big < 0.08:                                   # host mute toggles
+            mu = bool(rng.integers(0, 2)); d.set_mute(mu); [oo.set_mute(mu) for oo in o]
+        elif big < 0.14:                                 # a whole-state blob in the middle of the stream (bulk_params_apply)
+            blob = random_blob(rng, flavor, fs)
+            assert d.load_bulk(blob) == 0 and all(oo.load_bulk(blob) == 0 for oo in o)
+        elif big < 0.18:                                 # preset load: delay lines cleared, preset mute envelope (flash_storage.c:832, main.c:449-458)
+            ref = Oracle(flavor); ref.set_rate(fs); ref.load_bulk(random_blob(rng, flavor, fs)); image = ref.save_slot(0); ref.close()
+            assert d.load_slot(image) == 0 and all(oo.load_slot(image) == 0 for oo in o)
+        elif big < 0.21:
+            d.factory_defaults(); [oo.factory_defaults() for oo in o]
         if k == n_steps // 2:
             fs, Bs = RATES[(seed + 1) % 3]
             B = int(rng.choice(Bs))
