@@ -166,3 +166,36 @@ def test_random_request_sequences(flavor, seed):
             assert np.array_equal(rp, pairs[s]) and np.array_equal(rs, sub[s]) and np.array_equal(rk, peaks[s]), f"step {k} stream {s}"
             assert o[s].status() == d.status(s), f"step {k} stream {s}: status"
     d.close()
+
+
+@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 6))))
+def test_output_pointer_and_layout_combinations(flavor, seed):
+    """dspi_process with any subset of {pairs, sub, peaks} requested, in either layout, 16- or 24-bit input, must hand back
+    exactly what a full stream-major call returns (one context per variant, same input, two launches each)."""
+    from dspi_amd.host import Dspi
+    from dspi_amd import workloads as WL
+    rng = np.random.default_rng(4200 + 100 * flavor + seed)
+    fs, Bs = RATES[seed % 3]
+    B = int(rng.choice(Bs)); blocks = int(rng.integers(3, 9)); S = int(rng.choice([5, 70, 131]))
+    depth = 16 if rng.random() < 0.5 else 24
+    blob = random_blob(rng, flavor, fs)
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs, first_stream=int(rng.integers(0, 20)))
+    data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm)
+    half = (lambda c: data[:, c * blocks * B:(c + 1) * blocks * B]) if depth == 16 else (lambda c: data[:, c * blocks * B * 6:(c + 1) * blocks * B * 6])
+
+    def run(**kw):
+        d = Dspi(flavor, S, device=0); assert d.set_rate(fs) == 0; d.set_volume(-9 * 256); assert d.load_bulk(blob) == 0
+        outs = [d.process_host(np.ascontiguousarray(half(c)), blocks, B, depth, **kw) for c in range(2)]
+        if kw.get("tiled"):
+            outs = [d.untile(p, s_) + (k,) for (p, s_, k) in outs]
+        d.close()
+        return outs
+    full = run()
+    for _ in range(4):
+        kw = dict(want_pairs=bool(rng.integers(0, 2)), want_sub=bool(rng.integers(0, 2)), want_peaks=bool(rng.integers(0, 2)), tiled=bool(rng.integers(0, 2)))
+        got = run(**kw)
+        for c in range(2):
+            for name, a_, b_ in zip(("pairs", "sub", "peaks"), full[c], got[c]):
+                if b_ is not None:
+                    assert np.array_equal(a_, b_), f"{name} differ with {kw}, launch {c}"
