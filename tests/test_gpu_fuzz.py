@@ -199,3 +199,38 @@ def test_output_pointer_and_layout_combinations(flavor, seed):
             for name, a_, b_ in zip(("pairs", "sub", "peaks"), full[c], got[c]):
                 if b_ is not None:
                     assert np.array_equal(a_, b_), f"{name} differ with {kw}, launch {c}"
+
+
+@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 4))))
+def test_random_preset_per_stream(flavor, seed):
+    """Every stream loads its own random blob: band kinds, flags, delays and leveller / crossfeed / loudness settings all
+    differ from lane to lane inside one workgroup (per-lane parameter kernels, SIMT divergence on the band forms); a few
+    streams keep a shared blob so that packed rows and per-lane rows coexist in one launch."""
+    from dspi_amd.host import Dspi
+    from dspi_amd import workloads as WL
+    from orclib import Oracle
+    rng = np.random.default_rng(9100 + 100 * flavor + seed)
+    fs, Bs = RATES[seed % 3]
+    B = int(rng.choice(Bs)); blocks = int(rng.integers(4, 10)); S = int(rng.choice([9, 40, 140]))
+    depth = 16 if rng.random() < 0.5 else 24
+    shared = random_blob(rng, flavor, fs)
+    d = Dspi(flavor, S, device=0); assert d.set_rate(fs) == 0; d.set_volume(-6 * 256); assert d.load_bulk(shared) == 0
+    blobs = {}
+    for s in range(S):
+        if rng.random() < 0.7:
+            blobs[s] = random_blob(rng, flavor, fs)
+            assert d.load_bulk(blobs[s], stream=s) == 0
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs, first_stream=int(rng.integers(0, 20)))
+    data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm)
+    step = blocks * B * (1 if depth == 16 else 6)        # int16 [S][frames][2] or bytes [S][frames * 6]
+    outs = [d.process_host(np.ascontiguousarray(data[:, c * step:(c + 1) * step]), blocks, B, depth) for c in range(2)]
+    pairs = np.concatenate([o_[0] for o_ in outs], axis=2); sub = np.concatenate([o_[1] for o_ in outs], axis=1); peaks = np.concatenate([o_[2] for o_ in outs], axis=1)
+    for s in sorted(set(int(x) for x in rng.integers(0, S, 12))):
+        o = Oracle(flavor, detmath=True); assert o.set_rate(fs) == 0; o.set_volume(-6 * 256); assert o.load_bulk(shared) == 0
+        if s in blobs: assert o.load_bulk(blobs[s]) == 0
+        rp, rs, rk, _ = o.process(data[s], blocks * 2, B, depth)
+        assert np.array_equal(rp, pairs[s]) and np.array_equal(rs, sub[s]) and np.array_equal(rk, peaks[s]), f"stream {s} ({'own' if s in blobs else 'shared'} blob)"
+        assert o.status() == d.status(s), f"stream {s}: status"
+        o.close()
+    d.close()
