@@ -167,8 +167,9 @@ int rebuild_assignment(dspi_ctx *c) {
 
 int rebuild_launch_lists(dspi_ctx *c) {
     // lists 0 (Q28) and 1 (float lanes whose two streams share an image): one item per (row, image), grouped by leveller
-    // on/off for the float kernel variants.  Lists 2 / 3 (float lanes with ONE stream of an image, first / second
-    // stream): the one-stream float kernel reads every lane's own image, so all images of a row merge into one item.
+    // on/off for the float kernel variants.  List 2 (float lanes with ONE stream of an image — image_items 2 / 3 = first /
+    // second stream, WgItem::image = which; Q28: rows holding several images): the per-lane parameter kernels read every
+    // lane's own image, so all images of a row merge into one item.  Launch list 3 stays empty.
     size_t total = 0;
     for (int lev = 0; lev < 2; lev++)
         for (int k = 0; k < 4; k++) {
