@@ -138,6 +138,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP kernel is the only audio path")
+    local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -145,12 +150,10 @@ def main():
         # RCCL ("nccl") over xGMI; DSPI_BENCH_BACKEND=gloo exists only to smoke-test the multi-rank control flow on a
         # box with fewer GPUs than ranks (ranks then share devices)
         backend = os.environ.get("DSPI_BENCH_BACKEND", "nccl")
-        dist.init_process_group(backend, rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP kernel is the only audio path")
-    local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     FS, B = 96000, 96
     S, NB = args.streams, args.blocks_per_step
