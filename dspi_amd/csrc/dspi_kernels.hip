@@ -1438,15 +1438,21 @@ size_t chain_lds_bytes(int flavor, int packed) {
     return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox : (flavor ? 0 : 6))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);
 }
 
+constexpr int kMaxDevices = 65;      // slot 64: any device index beyond (attribute set on every launch)
+
 template <int FLAVOR, bool PL>
 static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(FLAVOR, 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device function attribute: remember it per device (contexts on several GPUs may
+    // share one process; a context is single-threaded)
+    static bool attr_set[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
+    if (!attr_set[dev] || dev == kMaxDevices - 1) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, false, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, true, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<FLAVOR, true, PL>), dim3(n_items), dim3(256), lds, stream, args);
     else hipLaunchKernelGGL((chain_kernel<FLAVOR, false, PL>), dim3(n_items), dim3(256), lds, stream, args);
@@ -1456,11 +1462,13 @@ static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_
 template <bool TAIL, bool LEV, bool PCM24, bool TILED>
 static hipError_t launch_chain_pk_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(1, 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[kMaxDevices] = {};      // per device, see launch_chain_t
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
+    if (!attr_set[dev] || dev == kMaxDevices - 1) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24, TILED>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
     return hipGetLastError();
