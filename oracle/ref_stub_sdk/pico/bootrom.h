@@ -1,0 +1,3 @@
+/* oracle/ref_stub_sdk/pico/bootrom.h — host stand-in for the un-vendored pico-sdk header of the same name (TEST INFRASTRUCTURE, see pico_stub_all.h). */
+#pragma once
+#include "pico_stub_all.h"

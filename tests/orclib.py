@@ -24,23 +24,48 @@ def _build():
     subprocess.run(["make", "-C", str(ORC_DIR), "-s"], check=True)
 
 
-def ref_available(flavor: int) -> bool:
-    return (ORC_DIR / "_ref" / f"libref_{'f32' if flavor else 'q28'}.so").exists()
+def ref_available(flavor: int, kind="ref", fma: bool = False) -> bool:
+    """kind "ref": reference leaf sources under our orchestrator; "fw": the firmware build (usb_audio.c, flash_storage.c,
+    pdm_generator.c compiled in place, oracle/ref_fw.c).  fma: built with the firmware's float contract (float flavour only)."""
+    return _ref_path(flavor, kind, fma).exists()
 
 
-def load(flavor: int, ref: bool = False) -> C.CDLL:
-    key = (flavor, ref)
-    if key in _libs:
+def _ref_path(flavor: int, kind, fma: bool) -> Path:
+    name = ("f32" if flavor else "q28") + ("_fma" if fma else "")
+    return ORC_DIR / "_ref" / (f"libref_fw_{name}.so" if kind == "fw" else f"libref_{name}.so")
+
+
+_fw_tmp = None
+_fw_count = 0
+
+
+def _private_copy(path: Path) -> str:
+    """The firmware build keeps one device in file-scope globals: every Oracle gets its own copy of the library."""
+    global _fw_tmp, _fw_count
+    import shutil, tempfile
+    if _fw_tmp is None:
+        _fw_tmp = tempfile.TemporaryDirectory(prefix="dspi_fw_")
+    _fw_count += 1
+    dst = Path(_fw_tmp.name) / f"{path.stem}_{_fw_count}.so"
+    shutil.copyfile(path, dst)
+    return str(dst)
+
+
+def load(flavor: int, ref=False, fma: bool = False) -> C.CDLL:
+    key = (flavor, ref, fma)
+    if key in _libs and ref != "fw":
         return _libs[key]
     name = "f32" if flavor else "q28"
     if ref:
-        path = ORC_DIR / "_ref" / f"libref_{name}.so"
+        path = _ref_path(flavor, ref, fma)
         if not path.exists() and Path("/root/reference/firmware/DSPi").is_dir():
             subprocess.run(["make", "-C", str(ORC_DIR), "-s", "ref"], check=True)
+        if ref == "fw":
+            path = Path(_private_copy(path))
     else:
         _build()
         path = ORC_DIR / f"liborc_{name}.so"
-    # RTLD_LOCAL + distinct files: the four builds export identical symbol names
+    # RTLD_LOCAL + distinct files: the builds export identical symbol names
     lib = C.CDLL(str(path), mode=os.RTLD_LOCAL)
     lib.orc_new.restype = C.c_void_p
     lib.orc_free.argtypes = [C.c_void_p]
@@ -62,22 +87,37 @@ def load(flavor: int, ref: bool = False) -> C.CDLL:
     lib.orc_scalar.argtypes = [C.c_void_p, C.c_int]
     lib.orc_scalar_f.argtypes = [C.c_void_p, C.c_int]
     lib.orc_scalar_f.restype = C.c_float
-    assert lib.orc_flavor() == flavor and lib.orc_is_ref_build() == int(ref)
-    _libs[key] = lib
+    assert lib.orc_flavor() == flavor and lib.orc_is_ref_build() == (2 if ref == "fw" else int(bool(ref)))
+    if hasattr(lib, "orc_set_fma_mode"): lib.orc_set_fma_mode.argtypes = [C.c_int]
+    if ref == "fw":
+        lib.orc_boot_from_flash.argtypes = [C.c_void_p, C.c_uint32]
+        lib.orc_read_flash.argtypes = [C.c_void_p]
+        lib.orc_pdm_ref_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    else:
+        _libs[key] = lib
     return lib
 
 
 class Oracle:
     """One DSPi device (= one stereo stream)."""
 
-    def __init__(self, flavor: int, ref: bool = False, detmath: bool = True, x86_casts: bool = False):
-        self.lib = load(flavor, ref)
+    def __init__(self, flavor: int, ref=False, detmath: bool = True, x86_casts: bool = False, fma: bool = False, flash: bytes = None):
+        """ref: False = standalone restatement, True = reference leaf sources (_ref), "fw" = firmware build (ref_fw.c).
+        fma: the firmware's float contract (contraction on).  The standalone build switches at run time
+        (orc_set_fma_mode, explicit fmaf in the pattern GCC produces); the reference builds are separate libraries.
+        flash: (fw only) boot from this 48 KB preset area instead of an erased flash."""
+        self.lib = load(flavor, ref, fma if ref else False)
         self.flavor = flavor
+        self.fma = fma
         self.lib.orc_set_math_mode(1 if detmath else 0)
         self.lib.orc_set_x86_cast_semantics(1 if x86_casts else 0)
+        if hasattr(self.lib, "orc_set_fma_mode") and ref != "fw":
+            self.lib.orc_set_fma_mode(1 if fma else 0)
         self.C = self.lib.orc_num_channels()
         self.N = self.lib.orc_num_outputs()
         self.P = self.lib.orc_num_pairs()
+        if flash is not None:
+            assert ref == "fw" and self.lib.orc_boot_from_flash(flash, len(flash)) == 0
         self.h = self.lib.orc_new()
 
     def close(self):
@@ -117,6 +157,11 @@ class Oracle:
 
     def load_slot(self, image: bytes, expect_slot: int = -1) -> int:
         return self.lib.orc_load_preset_slot(self.h, image, len(image), expect_slot)
+
+    def read_flash(self) -> bytes:
+        buf = C.create_string_buffer(12 * 4096)
+        self.lib.orc_read_flash(buf)
+        return buf.raw
 
     def load_flash_dump(self, dump: bytes) -> int:
         return self.lib.orc_load_flash_dump(self.h, dump, len(dump))
