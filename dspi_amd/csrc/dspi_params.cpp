@@ -193,6 +193,10 @@ void Params::boot() {
     rate_changed(freq);
     service();
     memset(&ops, 0, sizeof(ops));     // nothing has run yet: state starts zeroed by the context
+    // First boot on an erased flash writes the fresh directory (preset_boot_load -> dir_flush, flash_storage.c:1086-1090),
+    // and every flash_write_sector re-arms the preset mute for flash_mute_hold_samples() = max(10 ms, 512) samples at the
+    // power-on rate of 44.1 kHz (:262-266, :349-350): a new device starts with 512 muted samples and the fade-in.
+    pipeline_mute(512);
     dirty = true;
 }
 
@@ -558,6 +562,7 @@ void Params::apply_master_from_mode(bool have_slot, uint16_t slot_version, float
 void Params::pipeline_mute(uint32_t samples) {   // prepare_pipeline_reset, main.c:449-458
     ops.mute_start = 1;
     ops.mute_samples = samples;
+    ops.mute_cancel = 0;            // preset_loading = true again: the last writer wins, as the firmware's flag does
 }
 
 void Params::transition_core1() {   // derive_core1_mode, usb_audio.c:1620-1630
@@ -827,6 +832,12 @@ int Params::load_slot(const void *image, size_t len, int expect_slot) {
     recalc_all_filters(fs); update_delay_samples(fs);
     ops.zero_delay_lines = 1;              // flash_storage.c:832
     transition_core1();
+    // preset_load ends by writing the directory (flash_storage.c:846-847) and every flash_write_sector re-arms the mute
+    // for flash_mute_hold_samples() = max(10 ms, 512 samples) (:262-266, :349-350)
+    {
+        uint64_t hold = ((uint64_t)freq * 10u + 999u) / 1000u;
+        pipeline_mute(hold < 512u ? 512u : (uint32_t)hold);
+    }
     service();
     return 0;
 }

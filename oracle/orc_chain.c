@@ -445,6 +445,11 @@ static void prepare_pipeline_reset(orc_ctx *c, uint32_t mute_samples) { /* main.
 }
 
 static void transition_core1(orc_ctx *c) { c->core1_mode = derive_core1_mode_(c); }
+static uint32_t flash_mute_hold_samples_(uint32_t freq) { /* flash_storage.c:262-266 */
+    uint64_t samples = ((uint64_t)freq * 10u + 999u) / 1000u;
+    if (samples < 512u) samples = 512u;
+    return (uint32_t)samples;
+}
 
 /* ------------------------------------------------------------------------------------- */
 /* Factory defaults / presets / bulk blobs                                                 */
@@ -1061,7 +1066,10 @@ orc_ctx *orc_new(void) {
     apply_factory_defaults(c);           /* matrix_init_defaults + dsp_init_default_filters are subsets of this */
     recalculate_all_filters(c, 48000.0f);
     set_volume_(c, 0);
-    /* core0_init (main.c:645-696): preset_boot_load on blank flash = factory defaults */
+    /* core0_init (main.c:645-696): preset_boot_load on blank flash = factory defaults, and the fresh directory is written
+     * (flash_storage.c:1086-1090): flash_write_sector re-arms the preset mute for flash_mute_hold_samples() = max(10 ms, 512)
+     * samples at the power-on 44.1 kHz (:262-266, :349-350) — found by running the firmware build (tests/test_oracle_vs_fw.py) */
+    prepare_pipeline_reset(c, 512);
     recalculate_all_filters(c, 48000.0f); update_delay_samples(c, 48000.0f);
     loudness_recompute(c, 48000.0f); c->loudness_recompute_pending = false;
     if (c->loudness_enabled) set_volume_(c, c->audio_state.volume);
@@ -1147,6 +1155,10 @@ int orc_load_preset_slot(orc_ctx *c, const void *image, uint32_t len, int expect
         recalculate_all_filters(c, fs); update_delay_samples(c, fs);
         memset(c->delay_lines, 0, sizeof(c->delay_lines));
         transition_core1(c);
+        /* preset_load ends by writing the directory (last_active_slot, flash_storage.c:846-847); every flash_write_sector
+         * re-arms the mute for flash_mute_hold_samples() = max(10 ms, 512 samples) (:262-266, :349-350) — the hold after a
+         * preset load is that, not PRESET_MUTE_SAMPLES (found by running the firmware build, tests/test_oracle_vs_fw.py) */
+        prepare_pipeline_reset(c, flash_mute_hold_samples_(c->audio_state.freq));
         service(c);
     }
     orc_leave(csr);
@@ -1478,6 +1490,12 @@ const void *orc_tap(orc_ctx *c, int what, int *bytes) {
         case 6: *bytes = (int)sizeof(c->leveller_state); return &c->leveller_state;
         case 7: *bytes = (int)sizeof(c->filter_recipes); return c->filter_recipes;
         case 8: *bytes = (int)sizeof(c->delay_lines); return c->delay_lines;
+        case 9: *bytes = (int)sizeof(c->channel_bypassed); return c->channel_bypassed;
+#if PICO_RP2350
+        case 10: *bytes = (int)sizeof(c->loudness_state); return c->loudness_state;
+#else
+        case 10: *bytes = (int)sizeof(c->loudness_biquads); return c->loudness_biquads;
+#endif
         default: *bytes = 0; return NULL;
     }
 }

@@ -431,8 +431,14 @@ const void *orc_tap(orc_ctx *c, int what, int *bytes) {
 int orc_scalar(orc_ctx *c, int what) {
     (void)c;
     switch (what) {
-        case 0: return (current_loudness_coeffs && loudness_active_table)
-                       ? (int)((current_loudness_coeffs - &loudness_active_table[0][0]) / LOUDNESS_BIQUAD_COUNT) : -1;
+        case 0: {   /* row of current_loudness_coeffs, whichever of the two table buffers it points into (loudness.c:5-10) */
+            extern LoudnessCoeffs loudness_tables[2][LOUDNESS_VOL_STEPS][LOUDNESS_BIQUAD_COUNT];
+            if (!current_loudness_coeffs) return -1;
+            return (int)(((current_loudness_coeffs - &loudness_tables[0][0][0]) / LOUDNESS_BIQUAD_COUNT) % LOUDNESS_VOL_STEPS);
+        }
+        case 12:    /* 1 = loudness is on while the coefficient pointer is outside the active table (would be a stale table) */
+            return loudness_enabled && current_loudness_coeffs && loudness_active_table &&
+                   (current_loudness_coeffs < &loudness_active_table[0][0] || current_loudness_coeffs >= &loudness_active_table[LOUDNESS_VOL_STEPS][0]);
         case 1: return (int)core1_mode;
         case 2: return any_delay_active;
         case 3: return (int)delay_write_idx;

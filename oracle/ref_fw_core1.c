@@ -91,10 +91,13 @@ int fw_core1_take_sub(int32_t *dst, int max) {
 
 /* ---- the PDM modulator as a stream: n Q28 samples in, 8 x 32 PDM bits per sample out ---- */
 static uint32_t fw_pdm_rd;                         /* next DMA-ring word not yet handed out */
-void orc_pdm_ref_restart(void) {                   /* a fresh entry into pdm_processing_loop = hardware restart (:248-281) */
+static void fw_pdm_start(int reseed);
+void orc_pdm_ref_restart(void) { fw_pdm_start(1); }            /* power-on */
+void orc_pdm_ref_restart_keep_rng(void) { fw_pdm_start(0); }   /* re-enable: every local is reset, the file-scope PRNG is not (:63, :241-252) */
+static void fw_pdm_start(int reseed) {             /* a fresh entry into pdm_processing_loop = hardware restart (:248-281) */
     if (pdm_dma_chan < 0) pdm_dma_chan = 0;
     pdm_tail = pdm_head = 0;
-    rng_state = 123456789;                         /* the file-scope PRNG seed (:63); a device restart keeps it, a test restarts it */
+    if (reseed) rng_state = 123456789;             /* the file-scope PRNG seed (:63) */
     core1_mode = CORE1_MODE_PDM; pdm_enabled = true;
     pdm_stats_write_idx = 0;
     fw_c1_kind = 2; fw_c1_alive = 1;

@@ -77,7 +77,10 @@ static inline void __dmb(void) { __asm__ volatile("" ::: "memory"); }
 static inline void __dsb(void) { __asm__ volatile("" ::: "memory"); }
 static inline void __isb(void) { __asm__ volatile("" ::: "memory"); }
 static inline void __sev(void) {}
-static inline void __wfe(void) {}
+#ifndef ORC_WFE                      /* each wrapper TU says what "wait for the other core" means (ref_fw.c, ref_fw_core1.c) */
+#define ORC_WFE() ((void)0)
+#endif
+static inline void __wfe(void) { ORC_WFE(); }
 static inline void __wfi(void) {}
 uint32_t save_and_disable_interrupts(void);
 void restore_interrupts(uint32_t status);

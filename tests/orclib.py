@@ -93,6 +93,7 @@ def load(flavor: int, ref=False, fma: bool = False) -> C.CDLL:
         lib.orc_boot_from_flash.argtypes = [C.c_void_p, C.c_uint32]
         lib.orc_read_flash.argtypes = [C.c_void_p]
         lib.orc_pdm_ref_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.orc_pdm_ref_restart.restype = None; lib.orc_pdm_ref_restart_keep_rng.restype = None
     else:
         _libs[key] = lib
     return lib
