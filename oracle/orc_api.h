@@ -21,6 +21,9 @@ int orc_num_pairs(void);         /* 4 / 2 */
 int orc_preset_slot_size(void);
 void orc_set_math_mode(int detmath);        /* leveller per-block log10f/powf: 0 glibc, 1 dspi_detmath.h */
 void orc_set_x86_cast_semantics(int on);    /* see orc_common.h */
+void orc_set_fma_mode(int on);              /* float contract of the restated code: 0 canonical, 1 firmware as built (orc_leaf.c);
+                                             * the _ref / firmware builds take theirs from the compiler flags and only switch the
+                                             * restated orchestrator */
 
 orc_ctx *orc_new(void);          /* power-on state: factory defaults, 44.1 kHz, host volume 0 dB */
 void orc_free(orc_ctx *);

@@ -58,6 +58,17 @@ extern int orc_math_mode;
 
 int orc_x86_cast_semantics = 0;
 
+/* Float contract of the code restated in this file (see orc_leaf.c for the rule): the four places where the firmware's
+ * compiler fuses a multiply into an add outside the leaf functions — the loudness SVF (usb_audio.c:697-712), the matrix mix
+ * (:766), the sub-alignment term of dsp_update_delay_samples (dsp_pipeline.c:227-228) and the Taylor dB->linear of the bulk
+ * path (bulk_params.c:54).  Pinned by tests/test_oracle_vs_fw.py against usb_audio.c compiled with contraction on. */
+extern int orc_fma_mode;
+#if PICO_RP2350
+#define OMAD(a, b, c) (orc_fma_mode ? fmaf((a), (b), (c)) : (a) * (b) + (c))
+#else
+#define OMAD(a, b, c) ((a) * (b) + (c))
+#endif
+
 #if PICO_RP2350
 _Static_assert(sizeof(Biquad) == 68, "float Biquad layout");
 #else
@@ -325,8 +336,7 @@ static void update_delay_samples(orc_ctx *c, float fs) { /* dsp_pipeline.c:216-2
     for (int o = 0; o < NUM_DELAY_CHANNELS; o++) {
         float ms = c->channel_delays_ms[CH_OUT_1 + o];
         if (o == NUM_DELAY_CHANNELS - 1) {
-            float align = (float)SUB_ALIGN_SAMPLES / fs * 1000.0f;
-            ms += align;
+            ms = OMAD((float)SUB_ALIGN_SAMPLES / fs, 1000.0f, ms);      /* ms += 128 / fs * 1000 */
         }
         int32_t s = orc_f2i(ms * fs / 1000.0f);
         if (s > MAX_DELAY_SAMPLES) s = MAX_DELAY_SAMPLES;
@@ -630,7 +640,8 @@ static float db_to_linear_taylor(float db) {
     if (db < -60.0f) db = -60.0f;
     if (db > 20.0f) db = 20.0f;
     float x = db * 0.1151292546f;
-    float lin = 1.0f + x + x * x * 0.5f + x * x * x * 0.1666667f + x * x * x * x * 0.0416667f;
+    float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+    float lin = OMAD(x4, 0.0416667f, OMAD(x3, 0.1666667f, OMAD(x2, 0.5f, 1.0f + x)));
     return (lin < 0.0f) ? 0.0f : lin;
 }
 
@@ -830,11 +841,11 @@ static void process_packet(orc_ctx *c, const uint8_t *data, uint32_t n, int bit_
                     if (lc->bypass) continue;
                     LoudnessSvfState *st = &c->loudness_state[ch][j];
                     float v3 = x[ch] - st->ic2eq;
-                    float v1 = lc->sva1 * st->ic1eq + lc->sva2 * v3;
-                    float v2 = st->ic2eq + lc->sva2 * st->ic1eq + lc->sva3 * v3;
-                    st->ic1eq = 2.0f * v1 - st->ic1eq;
-                    st->ic2eq = 2.0f * v2 - st->ic2eq;
-                    x[ch] = lc->svm0 * x[ch] + lc->svm1 * v1 + lc->svm2 * v2;
+                    float v1 = OMAD(lc->sva1, st->ic1eq, lc->sva2 * v3);
+                    float v2 = OMAD(lc->sva3, v3, OMAD(lc->sva2, st->ic1eq, st->ic2eq));
+                    st->ic1eq = OMAD(2.0f, v1, -st->ic1eq);
+                    st->ic2eq = OMAD(2.0f, v2, -st->ic2eq);
+                    x[ch] = OMAD(lc->svm2, v2, OMAD(lc->svm0, x[ch], lc->svm1 * v1));
                 }
             buf_l[i] = x[0]; buf_r[i] = x[1];
         }
@@ -918,7 +929,7 @@ static void process_packet(orc_ctx *c, const uint8_t *data, uint32_t n, int bit_
         float gl = 0.0f, gr = 0.0f;
         if (xl->enabled) gl = xl->phase_invert ? -xl->gain_linear : xl->gain_linear;
         if (xr->enabled) gr = xr->phase_invert ? -xr->gain_linear : xr->gain_linear;
-        if (gl != 0.0f && gr != 0.0f) for (uint32_t i = 0; i < n; i++) dst[i] = buf_l[i] * gl + buf_r[i] * gr;
+        if (gl != 0.0f && gr != 0.0f) for (uint32_t i = 0; i < n; i++) dst[i] = OMAD(buf_l[i], gl, buf_r[i] * gr);
         else if (gl != 0.0f) for (uint32_t i = 0; i < n; i++) dst[i] = buf_l[i] * gl;
         else if (gr != 0.0f) for (uint32_t i = 0; i < n; i++) dst[i] = buf_r[i] * gr;
         else memset(dst, 0, n * sizeof(float));
@@ -1045,6 +1056,7 @@ int orc_num_pairs(void) { return NUM_SPDIF_INSTANCES; }
 int orc_preset_slot_size(void) { return (int)sizeof(OrcPresetSlot); }
 void orc_set_math_mode(int detmath) { orc_math_mode = detmath; }
 void orc_set_x86_cast_semantics(int on) { orc_x86_cast_semantics = on; }
+void orc_set_fma_mode(int on) { orc_fma_mode = (on != 0) && PICO_RP2350; }
 
 orc_ctx *orc_new(void) {
     unsigned csr = orc_enter();

@@ -21,6 +21,21 @@
 
 int orc_math_mode = 0; /* 0: host libm (glibc) ; 1: dspi_detmath.h */
 
+/* Float contract.  0 = canonical: every multiply and add rounds on its own (-ffp-contract=off).
+ * 1 = the firmware as built: GNU C's default -ffp-contract=fast on a target with fused multiply-add (Cortex-M33 vfma,
+ * firmware/DSPi/CMakeLists.txt:6-11 sets only -O2/-O3), where GCC turns a*b + c into one fused operation.  Which pairs it
+ * fuses is decided on GIMPLE (tree-ssa-math-opts.c, pass widening_mul) and was read off `-fdump-tree-optimized` of the
+ * reference sources (oracle/Makefile FMA_FLAGS); every MAD() below is one of those `.FMA/.FMS/.FNMA` statements, written so
+ * that mode 0 evaluates the reference's expression with separate roundings and mode 1 with GCC's fused ones.
+ * tests/test_oracle_vs_ref.py and test_oracle_vs_fw.py hold this file to the reference compiled both ways, bit for bit.
+ * The RP2040 has no FPU and no fused operation: the Q28 flavour ignores the switch. */
+int orc_fma_mode = 0;
+#if PICO_RP2350
+#define MAD(a, b, c) (orc_fma_mode ? fmaf((a), (b), (c)) : (a) * (b) + (c))
+#else
+#define MAD(a, b, c) ((a) * (b) + (c))
+#endif
+
 static float lv_log10f(float x) { return orc_math_mode ? dspi_det_log10f(x) : log10f(x); }
 static float lv_powf(float a, float b) { return orc_math_mode ? dspi_det_powf(a, b) : powf(a, b); }
 
@@ -84,16 +99,16 @@ void orc_dsp_compute_coefficients(EqParamPacket *p, Biquad *bq, float fs) { /* :
         else if (p->type == FILTER_LOWSHELF) { float r = sqrtf(A); g = g / r; }
         else if (p->type == FILTER_HIGHSHELF) { float r = sqrtf(A); g = g * r; }
 
-        float c1 = 1.0f / (1.0f + g * (g + k));
+        float c1 = 1.0f / MAD(g, g + k, 1.0f);                       /* 1 + g*(g+k) */
         float c2 = g * c1;
         float c3 = g * c2;
         float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
         switch (p->type) {
             case FILTER_LOWPASS:   m0 = 0.0f;  m1 = 0.0f;               m2 = 1.0f;          break;
             case FILTER_HIGHPASS:  m0 = 1.0f;  m1 = -k;                 m2 = -1.0f;         break;
-            case FILTER_PEAKING:   m0 = 1.0f;  m1 = k * (A * A - 1.0f); m2 = 0.0f;          break;
-            case FILTER_LOWSHELF:  m0 = 1.0f;  m1 = k * (A - 1.0f);     m2 = A * A - 1.0f;  break;
-            case FILTER_HIGHSHELF: m0 = A * A; m1 = k * (1.0f - A) * A; m2 = 1.0f - A * A;  break;
+            case FILTER_PEAKING:   m0 = 1.0f;  m1 = k * MAD(A, A, -1.0f); m2 = 0.0f;        break;
+            case FILTER_LOWSHELF:  m0 = 1.0f;  m1 = k * (A - 1.0f);     m2 = MAD(A, A, -1.0f); break;
+            case FILTER_HIGHSHELF: m0 = A * A; m1 = k * (1.0f - A) * A; m2 = 1.0f - m0;     break;   /* A*A is shared: no fusion */
             default: break;
         }
         bq->sva1 = c1; bq->sva2 = c2; bq->sva3 = c3;
@@ -119,22 +134,28 @@ void orc_dsp_compute_coefficients(EqParamPacket *p, Biquad *bq, float fs) { /* :
             b0 = (1 + cs) / 2; b1 = -(1 + cs); b2 = (1 + cs) / 2;
             a0 = 1 + alpha; a1 = -2 * cs; a2 = 1 - alpha; break;
         case FILTER_PEAKING:
-            b0 = 1 + alpha * A; b1 = -2 * cs; b2 = 1 - alpha * A;
+            b0 = MAD(alpha, A, 1.0f); b1 = -2 * cs; b2 = MAD(-alpha, A, 1.0f);           /* 1 + alpha*A, 1 - alpha*A */
             a0 = 1 + alpha / A; a1 = -2 * cs; a2 = 1 - alpha / A; break;
-        case FILTER_LOWSHELF:
-            b0 = A * ((A + 1) - (A - 1) * cs + 2 * sqrtf(A) * alpha);
-            b1 = 2 * A * ((A - 1) - (A + 1) * cs);
-            b2 = A * ((A + 1) - (A - 1) * cs - 2 * sqrtf(A) * alpha);
-            a0 = (A + 1) + (A - 1) * cs + 2 * sqrtf(A) * alpha;
-            a1 = -2 * ((A - 1) + (A + 1) * cs);
-            a2 = (A + 1) + (A - 1) * cs - 2 * sqrtf(A) * alpha; break;
-        case FILTER_HIGHSHELF:
-            b0 = A * ((A + 1) + (A - 1) * cs + 2 * sqrtf(A) * alpha);
-            b1 = -2 * A * ((A - 1) + (A + 1) * cs);
-            b2 = A * ((A + 1) + (A - 1) * cs - 2 * sqrtf(A) * alpha);
-            a0 = (A + 1) - (A - 1) * cs + 2 * sqrtf(A) * alpha;
-            a1 = 2 * ((A - 1) - (A + 1) * cs);
-            a2 = (A + 1) - (A - 1) * cs - 2 * sqrtf(A) * alpha; break;
+        case FILTER_LOWSHELF: {
+            const float Ap = A + 1, Am = A - 1, t = Am * cs, S2 = 2 * sqrtf(A);
+            const float u = Ap - t, w = Ap + t;                                          /* the terms GCC keeps rounded */
+            b0 = A * MAD(S2, alpha, u);
+            b1 = 2 * A * MAD(-Ap, cs, Am);                                               /* (A-1) - (A+1)*cs */
+            b2 = A * MAD(-S2, alpha, u);
+            a0 = MAD(S2, alpha, w);
+            a1 = -2 * MAD(Ap, cs, Am);                                                   /* (A-1) + (A+1)*cs */
+            a2 = MAD(-S2, alpha, w); break;
+        }
+        case FILTER_HIGHSHELF: {
+            const float Ap = A + 1, Am = A - 1, t = Am * cs, S2 = 2 * sqrtf(A);
+            const float u = Ap + t, w = Ap - t;
+            b0 = A * MAD(S2, alpha, u);
+            b1 = -2 * A * MAD(Ap, cs, Am);
+            b2 = A * MAD(-S2, alpha, u);
+            a0 = MAD(S2, alpha, w);
+            a1 = 2 * MAD(-Ap, cs, Am);
+            a2 = MAD(-S2, alpha, w); break;
+        }
         default: break;
     }
 #if PICO_RP2350
@@ -166,15 +187,15 @@ void orc_dsp_process_channel_block(Biquad *bands, float *x, uint32_t n, uint8_t 
             for (uint32_t i = 0; i < n; i++) {
                 float in = x[i];
                 float v3 = in - e2;
-                float v1 = a1 * e1 + a2 * v3;
-                float v2 = e2 + a2 * e1 + a3 * v3;
-                e1 = 2.0f * v1 - e1;
-                e2 = 2.0f * v2 - e2;
+                float v1 = MAD(a1, e1, a2 * v3);                       /* a1*ic1 fused, a2*v3 rounded */
+                float v2 = MAD(a3, v3, MAD(a2, e1, e2));               /* (ic2 + a2*ic1) + a3*v3, both fused */
+                e1 = MAD(2.0f, v1, -e1);
+                e2 = MAD(2.0f, v2, -e2);
                 /* per-type output forms; the association below is the reference's */
                 if (ty == FILTER_LOWPASS) x[i] = v2;
-                else if (ty == FILTER_HIGHPASS) x[i] = in + m1 * v1 - v2;
-                else if (ty == FILTER_PEAKING) x[i] = in + m1 * v1;
-                else x[i] = m0 * in + m1 * v1 + m2 * v2;
+                else if (ty == FILTER_HIGHPASS) x[i] = MAD(m1, v1, in) - v2;
+                else if (ty == FILTER_PEAKING) x[i] = MAD(m1, v1, in);
+                else x[i] = MAD(m2, v2, MAD(m0, in, m1 * v1));         /* (m0*in + m1*v1) + m2*v2: m1*v1 rounded */
             }
             q->svic1eq = e1; q->svic2eq = e2;
         } else {
@@ -182,9 +203,9 @@ void orc_dsp_process_channel_block(Biquad *bands, float *x, uint32_t n, uint8_t 
             float s1 = q->s1, s2 = q->s2;
             for (uint32_t i = 0; i < n; i++) {
                 float in = x[i];
-                float y = b0 * in + s1;
-                s1 = b1 * in - a1 * y + s2;
-                s2 = b2 * in - a2 * y;
+                float y = MAD(b0, in, s1);
+                s1 = MAD(b1, in, -(a1 * y)) + s2;                      /* b1*in fused with the rounded a1*y; + s2 separate */
+                s2 = MAD(b2, in, -(a2 * y));
                 x[i] = y;
             }
             q->s1 = s1; q->s2 = s2;
@@ -220,7 +241,7 @@ void orc_leveller_compute_coefficients(LevellerCoeffs *out, const LevellerConfig
     if (amount < LEVELLER_AMOUNT_MIN) amount = LEVELLER_AMOUNT_MIN;
     if (amount > LEVELLER_AMOUNT_MAX) amount = LEVELLER_AMOUNT_MAX;
     float norm = amount / 100.0f;
-    out->ratio = 1.0f + norm * 19.0f;
+    out->ratio = MAD(norm, 19.0f, 1.0f);
     float mg = cfg->max_gain_db;
     if (mg < LEVELLER_MAX_GAIN_MIN) mg = LEVELLER_MAX_GAIN_MIN;
     if (mg > LEVELLER_MAX_GAIN_MAX) mg = LEVELLER_MAX_GAIN_MAX;
@@ -260,7 +281,7 @@ static float lv_block_gain_db(LevellerState *st, const LevellerCoeffs *c, float 
     }
     float a_s = (gc < st->gain_smooth_db) ? c->alpha_attack : c->alpha_release;
     float alpha = lv_powf(a_s, (float)count);
-    st->gain_smooth_db = alpha * st->gain_smooth_db + (1.0f - alpha) * gc;
+    st->gain_smooth_db = MAD(alpha, st->gain_smooth_db, (1.0f - alpha) * gc);
     return lv_powf(10.0f, st->gain_smooth_db / 20.0f);
 }
 
@@ -272,8 +293,8 @@ void orc_leveller_process_block(LevellerState *st, const LevellerCoeffs *c, cons
     const float a = c->alpha_rms, na = 1.0f - a;
     for (uint32_t i = 0; i < count; i++) {
         float sl = l[i], sr = r[i];
-        el = a * el + na * (sl * sl);
-        er = a * er + na * (sr * sr);
+        el = MAD(a, el, na * (sl * sl));
+        er = MAD(a, er, na * (sr * sr));
     }
     if (el < 1e-30f) el = 0.0f;
     if (er < 1e-30f) er = 0.0f;
@@ -383,7 +404,7 @@ void orc_crossfeed_compute_coefficients(CrossfeedState *st, const CrossfeedConfi
     if (cfg->itd_enabled) {
         float lp_delay = x / ((1.0f - x) * fs);
         float rem = CROSSFEED_ITD_SEC - lp_delay;
-        if (rem > 0.0f) { float D = rem * fs; ap = (1.0f - D) / (1.0f + D); }
+        if (rem > 0.0f) ap = MAD(-rem, fs, 1.0f) / MAD(rem, fs, 1.0f);      /* D = rem*fs: (1 - D) / (1 + D), D never rounded when fused */
         else ap = 1.0f;
     } else ap = 1.0f;
 #if PICO_RP2350
@@ -398,13 +419,13 @@ void orc_crossfeed_compute_coefficients(CrossfeedState *st, const CrossfeedConfi
 #if PICO_RP2350
 void orc_crossfeed_process_stereo(CrossfeedState *s, float *left, float *right) { /* :132-156 */
     float il = *left, ir = *right;
-    float lpl = s->lp_a0 * il + s->lp_b1 * s->lp_state_L;
-    float lpr = s->lp_a0 * ir + s->lp_b1 * s->lp_state_R;
+    float lpl = MAD(s->lp_a0, il, s->lp_b1 * s->lp_state_L);
+    float lpr = MAD(s->lp_a0, ir, s->lp_b1 * s->lp_state_R);
     s->lp_state_L = lpl; s->lp_state_R = lpr;
-    float apl = s->ap_a * lpl + s->ap_state_L;
-    s->ap_state_L = lpl - s->ap_a * apl;
-    float apr = s->ap_a * lpr + s->ap_state_R;
-    s->ap_state_R = lpr - s->ap_a * apr;
+    float apl = MAD(s->ap_a, lpl, s->ap_state_L);
+    s->ap_state_L = MAD(-s->ap_a, apl, lpl);
+    float apr = MAD(s->ap_a, lpr, s->ap_state_R);
+    s->ap_state_R = MAD(-s->ap_a, apr, lpr);
     *left = (il - lpl) + apr;
     *right = (ir - lpr) + apl;
 }
@@ -431,9 +452,9 @@ void orc_crossfeed_process_stereo(CrossfeedState *s, int32_t *left, int32_t *rig
 static float iso226_spl(float Tf, float af, float Lu, float phon) { /* loudness.c:37-50 */
     float B = 0.4f * powf(10.0f, (Tf + Lu) / 10.0f - 9.0f);
     float thr = powf(B, af);
-    float Af = 4.47e-3f * (powf(10.0f, 0.025f * phon) - 1.15f) + thr;
+    float Af = MAD(4.47e-3f, powf(10.0f, 0.025f * phon) - 1.15f, thr);
     if (Af < 1e-10f) Af = 1e-10f;
-    return (10.0f / af) * log10f(Af) - Lu + 94.0f;
+    return MAD(10.0f / af, log10f(Af), -Lu) + 94.0f;
 }
 
 static float loud_comp_db(float Tf, float af, float Lu, float ref, float eff, float pct) { /* :54-78 */
@@ -464,11 +485,11 @@ static void loud_shelf(float freq, float Q, float gain_db, int high, float fs, L
     float rA = sqrtf(A);
     if (high) g = g * rA; else g = g / rA;
     float k = 1.0f / Q;
-    o->sva1 = 1.0f / (1.0f + g * (g + k));
+    o->sva1 = 1.0f / MAD(g, g + k, 1.0f);
     o->sva2 = g * o->sva1;
     o->sva3 = g * o->sva2;
-    if (high) { o->svm0 = A * A; o->svm1 = k * (1.0f - A) * A; o->svm2 = 1.0f - A * A; }
-    else { o->svm0 = 1.0f; o->svm1 = k * (A - 1.0f); o->svm2 = A * A - 1.0f; }
+    if (high) { o->svm0 = A * A; o->svm1 = k * (1.0f - A) * A; o->svm2 = 1.0f - o->svm0; }      /* A*A shared: no fusion */
+    else { o->svm0 = 1.0f; o->svm1 = k * (A - 1.0f); o->svm2 = MAD(A, A, -1.0f); }
 #else
     float omega = 2.0f * PI_F * freq / fs;
     float sn = sinf(omega), cs = cosf(omega);

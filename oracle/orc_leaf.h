@@ -5,6 +5,7 @@
 #include "orc_types.h"
 
 extern int orc_math_mode;                 /* 0 libm, 1 detmath (leveller per-block step) */
+extern int orc_fma_mode;                  /* 0 canonical (no contraction), 1 the firmware's float contract (orc_leaf.c) */
 #if PICO_RP2350
 typedef float orc_sample;
 #else

@@ -43,6 +43,7 @@ uint16_t i2s_mck_multiplier = 128;
 /* leveller.c is compiled with -include ref_math_hook.h so the per-block
  * gain step can run on either math library without touching the reference source. */
 int orc_math_mode = 0;
+int orc_fma_mode = 0;        /* contract of the restated orchestrator; the reference objects have theirs from the compiler */
 #undef log10f
 #undef powf
 float orc_hook_log10f(float x) { return orc_math_mode ? dspi_det_log10f(x) : log10f(x); }

@@ -110,16 +110,22 @@ class Oracle:
         self.lib = load(flavor, ref, fma if ref else False)
         self.flavor = flavor
         self.fma = fma
-        self.lib.orc_set_math_mode(1 if detmath else 0)
-        self.lib.orc_set_x86_cast_semantics(1 if x86_casts else 0)
-        if hasattr(self.lib, "orc_set_fma_mode") and ref != "fw":
-            self.lib.orc_set_fma_mode(1 if fma else 0)
+        self.detmath, self.x86_casts, self.ref = detmath, x86_casts, ref
+        self._sync()
         self.C = self.lib.orc_num_channels()
         self.N = self.lib.orc_num_outputs()
         self.P = self.lib.orc_num_pairs()
         if flash is not None:
             assert ref == "fw" and self.lib.orc_boot_from_flash(flash, len(flash)) == 0
         self.h = self.lib.orc_new()
+
+    def _sync(self):
+        """The math / cast / contract switches are globals of the library, and Oracles of one build share the library:
+        every call re-asserts this Oracle's settings first."""
+        self.lib.orc_set_math_mode(1 if self.detmath else 0)
+        self.lib.orc_set_x86_cast_semantics(1 if self.x86_casts else 0)
+        if hasattr(self.lib, "orc_set_fma_mode") and self.ref != "fw":
+            self.lib.orc_set_fma_mode(1 if self.fma else 0)
 
     def close(self):
         if self.h:
@@ -133,30 +139,37 @@ class Oracle:
             pass
 
     def set_math(self, detmath: bool):
-        self.lib.orc_set_math_mode(1 if detmath else 0)
+        self.detmath = detmath
 
     def set_rate(self, hz: int) -> int:
+        self._sync()
         return self.lib.orc_set_sample_rate(self.h, hz)
 
     def set_volume(self, v: int):
+        self._sync()
         self.lib.orc_set_host_volume(self.h, v)
 
     def set_mute(self, m: bool):
+        self._sync()
         self.lib.orc_set_mute(self.h, int(m))
 
     def factory_defaults(self):
+        self._sync()
         self.lib.orc_factory_defaults(self.h)
 
     def load_bulk(self, blob) -> int:
+        self._sync()
         raw = blob.tobytes() if hasattr(blob, "tobytes") else bytes(blob)
         return self.lib.orc_load_bulk(self.h, raw, len(raw))
 
     def collect_bulk(self) -> bytes:
+        self._sync()
         buf = C.create_string_buffer(2896)
         self.lib.orc_collect_bulk(self.h, buf)
         return buf.raw
 
     def load_slot(self, image: bytes, expect_slot: int = -1) -> int:
+        self._sync()
         return self.lib.orc_load_preset_slot(self.h, image, len(image), expect_slot)
 
     def read_flash(self) -> bytes:
@@ -165,23 +178,28 @@ class Oracle:
         return buf.raw
 
     def load_flash_dump(self, dump: bytes) -> int:
+        self._sync()
         return self.lib.orc_load_flash_dump(self.h, dump, len(dump))
 
     def save_slot(self, slot_index: int = 0) -> bytes:
+        self._sync()
         n = self.lib.orc_preset_slot_size()
         buf = C.create_string_buffer(n)
         self.lib.orc_save_preset_slot(self.h, buf, slot_index)
         return buf.raw
 
     def vendor_set(self, req: int, wvalue: int, payload: bytes) -> int:
+        self._sync()
         return self.lib.orc_vendor_set(self.h, req, wvalue, payload, len(payload))
 
     def vendor_get(self, req: int, wvalue: int, cap: int = 64):
+        self._sync()
         buf = C.create_string_buffer(max(cap, 1))
         n = self.lib.orc_vendor_get(self.h, req, wvalue, buf, cap)
         return None if n < 0 else buf.raw[:n]
 
     def status(self) -> bytes:
+        self._sync()
         buf = C.create_string_buffer(self.C * 2 + 4)
         self.lib.orc_get_status(self.h, buf)
         return buf.raw
@@ -199,6 +217,7 @@ class Oracle:
 
     def process(self, pcm: np.ndarray, n_blocks: int, block_len: int, bit_depth: int = 16, want_peaks: bool = True):
         """pcm: int16 [frames][2] or uint8 [frames*6].  Returns (pairs [P][frames][2], sub [frames], peaks [blocks][C], clip)."""
+        self._sync()
         frames = n_blocks * block_len
         pcm = np.ascontiguousarray(pcm)
         assert pcm.nbytes == frames * (6 if bit_depth == 24 else 4), (pcm.nbytes, frames)

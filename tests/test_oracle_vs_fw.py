@@ -13,11 +13,15 @@ import orclib
 from orclib import Oracle
 from dspi_amd import wire as W, workloads as WL
 
-pytestmark = pytest.mark.skipif(not (orclib.ref_available(1, "fw") and orclib.ref_available(0, "fw")),
+pytestmark = pytest.mark.skipif(not (orclib.ref_available(1, "fw") and orclib.ref_available(0, "fw") and orclib.ref_available(1, "fw", True)),
                                 reason="oracle/_ref/libref_fw_* not built (needs /root/reference)")
 
-CASES = [(1, 48000, 48, 16), (1, 96000, 96, 16), (1, 44100, 45, 24), (1, 44100, 44, 16), (1, 96000, 97, 24),
-         (0, 48000, 48, 16), (0, 96000, 96, 24), (0, 44100, 45, 16), (0, 44100, 44, 24)]
+# (flavour, float contract): canonical float, float as the firmware is built (FMA contraction, oracle/orc_leaf.c), Q28
+FL = [(1, False), (1, True), (0, False)]
+
+CASES = [(1, 48000, 48, 16, False), (1, 96000, 96, 16, False), (1, 44100, 45, 24, False), (1, 44100, 44, 16, False), (1, 96000, 97, 24, False),
+         (1, 48000, 48, 24, True), (1, 96000, 96, 16, True), (1, 44100, 45, 16, True), (1, 44100, 44, 24, True),
+         (0, 48000, 48, 16, False), (0, 96000, 96, 24, False), (0, 44100, 45, 16, False), (0, 44100, 44, 24, False)]
 
 
 def pair(flavor, detmath=True, fma=False):
@@ -50,9 +54,9 @@ def signal(B, blocks, fs, first, depth):
     return pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm[None])[0]
 
 
-@pytest.mark.parametrize("flavor,fs,B,depth", CASES)
-def test_full_chain_is_process_audio_packet(flavor, fs, B, depth):
-    a, b = pair(flavor)
+@pytest.mark.parametrize("flavor,fs,B,depth,fma", CASES)
+def test_full_chain_is_process_audio_packet(flavor, fs, B, depth, fma):
+    a, b = pair(flavor, fma=fma)
     same_state(a, b, "power-on")
     blob = WL.full_chain_blob(flavor)
     for o in (a, b):
@@ -76,11 +80,11 @@ def test_glibc_math_and_sign_quirk_volume(flavor):
     same_audio(a, b, signal(48, 4, 48000, 3, 16), 4, 48, 16, "muted")
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
-def test_core1_eq_worker_twin(flavor):
+@pytest.mark.parametrize("flavor,fma", FL)
+def test_core1_eq_worker_twin(flavor, fma):
     """Sub output off, outputs 2.. on: the reference hands outputs 2..N-2 to Core 1 (usb_audio.c:782-872,
     pdm_generator.c:428-667 eq_worker_loop); the firmware build runs that loop, the oracle its single restatement."""
-    a, b = pair(flavor)
+    a, b = pair(flavor, fma=fma)
     blob = WL.full_chain_blob(flavor)
     N = a.N
     blob["outputs"][N - 1]["enabled"] = 0
@@ -102,14 +106,14 @@ def test_core1_eq_worker_twin(flavor):
     same_audio(a, b, signal(96, 10, 96000, 5, 16), 10, 96, 16, "PDM mode")
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("flavor,fma", FL)
 @pytest.mark.parametrize("seed", range(8))
-def test_random_presets(flavor, seed):
+def test_random_presets(flavor, fma, seed):
     from test_gpu_fuzz import random_blob, RATES
     rng = np.random.default_rng(31000 + 100 * flavor + seed)
     fs, Bs = RATES[seed % 3]
     B = int(rng.choice(Bs)); depth = 16 if rng.random() < 0.5 else 24
-    a, b = pair(flavor)
+    a, b = pair(flavor, fma=fma)
     blob = random_blob(rng, flavor, fs)
     for o in (a, b):
         assert o.set_rate(fs) == 0; o.set_volume(int(rng.choice([0, -5 * 256, -20 * 256, 3 * 256]))) if False else None
@@ -120,15 +124,15 @@ def test_random_presets(flavor, seed):
     same_audio(a, b, signal(B, 30, fs, int(rng.integers(0, 40)), depth), 30, B, depth, "random blob")
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("flavor,fma", FL)
 @pytest.mark.parametrize("seed", range(8))
-def test_random_request_sequences(flavor, seed):
+def test_random_request_sequences(flavor, fma, seed):
     """Random vendor SETs (in and out of range), UAC1 volume / mute, blobs, preset loads, factory resets and a rate change,
     each followed by audio: the reference's vendor_cmd_packet + main-loop semantics vs orc_vendor_set."""
     from test_gpu_fuzz import random_blob, random_request, RATES
     rng = np.random.default_rng(52000 + 100 * flavor + seed)
     fs, Bs = RATES[seed % 3]
-    a, b = pair(flavor)
+    a, b = pair(flavor, fma=fma)
     for o in (a, b):
         assert o.set_rate(fs) == 0; o.set_volume(-12 * 256); assert o.load_bulk(WL.full_chain_blob(flavor)) == 0
     B = int(rng.choice(Bs)); per = 5
@@ -147,7 +151,7 @@ def test_random_request_sequences(flavor, seed):
             blob = random_blob(rng, flavor, fs)
             assert a.load_bulk(blob) == 0 and b.load_bulk(blob) == 0
         elif big < 0.24:
-            ref = Oracle(flavor, x86_casts=True); ref.set_rate(fs); ref.load_bulk(random_blob(rng, flavor, fs)); image = ref.save_slot(3); ref.close()   # the cast switch is per library, not per context
+            ref = Oracle(flavor, x86_casts=True, fma=fma); ref.set_rate(fs); ref.load_bulk(random_blob(rng, flavor, fs)); image = ref.save_slot(3); ref.close()   # the cast switch is per library, not per context
             assert a.load_slot(image) == 0 and b.load_slot(image) == 0
         elif big < 0.28:
             a.factory_defaults(); b.factory_defaults()
@@ -158,11 +162,11 @@ def test_random_request_sequences(flavor, seed):
         same_audio(a, b, signal(B, per, fs, int(rng.integers(0, 40)), 16), per, B, 16, f"step {k}")
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
-def test_vendor_get_surface(flavor):
+@pytest.mark.parametrize("flavor,fma", FL)
+def test_vendor_get_surface(flavor, fma):
     """Every GET of the DSP subset answers with the same bytes (usb_audio.c:2271-2688)."""
     from test_gpu_fuzz import random_blob
-    a, b = pair(flavor)
+    a, b = pair(flavor, fma=fma)
     blob = random_blob(np.random.default_rng(9), flavor, 48000)
     for o in (a, b):
         assert o.set_rate(48000) == 0 and o.load_bulk(blob) == 0
@@ -194,13 +198,13 @@ def test_vendor_get_surface(flavor):
     assert a.status() == b.status()
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
-def test_preset_slot_images(flavor):
+@pytest.mark.parametrize("flavor,fma", FL)
+def test_preset_slot_images(flavor, fma):
     """collect_live_state / apply_slot_to_live / CRC (flash_storage.c:464-742): slot images byte for byte, and a slot saved by
     either side loads identically into both; a corrupt image is rejected by both and cancels the preset mute."""
     from test_gpu_fuzz import random_blob
     rng = np.random.default_rng(77 + flavor)
-    a, b = pair(flavor)
+    a, b = pair(flavor, fma=fma)
     for trial in range(4):
         blob = random_blob(rng, flavor, 48000)
         mv = struct.pack("<f", float(rng.uniform(-40, 0)))

@@ -63,3 +63,30 @@ def test_control_surface_matches(flavor):
     for field, val, code in (("format_version", 7, -1), ("format_version", 1, -1), ("platform_id", 1 - flavor, -2), ("num_channels", 3, -3), ("payload_length", 100, -4)):
         bl = blob.copy(); bl["header"][field] = val
         assert a.load_bulk(bl) == code and b.load_bulk(bl) == code
+
+
+@pytest.mark.skipif(not orclib.ref_available(1, "ref", True), reason="oracle/_ref/libref_f32_fma.so not built")
+@pytest.mark.parametrize("fs,B,depth", [(48000, 48, 16), (96000, 96, 24), (44100, 45, 16)])
+def test_firmware_float_contract(fs, B, depth):
+    """The float flavour as the firmware is built — GCC's FMA contraction (oracle/Makefile FMA_FLAGS): the standalone oracle's
+    explicit fused pattern (orc_leaf.c MAD) against the reference leaf sources compiled with contraction on; coefficients
+    of every design function and every output word."""
+    a = Oracle(1, ref=False, detmath=True, x86_casts=True, fma=True); b = Oracle(1, ref=True, detmath=True, x86_casts=True, fma=True)
+    canon = Oracle(1, ref=False, detmath=True, x86_casts=True)
+    blob = WL.full_chain_blob(1)
+    for o in (a, b, canon):
+        assert o.set_rate(fs) == 0
+        o.set_volume(-12 * 256)
+        assert o.load_bulk(blob) == 0
+    for t in range(9):
+        assert a.tap(t) == b.tap(t), f"state tap {t}"
+    differs = 0
+    for first in (2, 15, 16, 18, 19):
+        pcm = WL.synth_pcm16(1, B * 25, fs, first_stream=first)[0]
+        data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm[None])[0]
+        ra, rb, rc = a.process(data, 25, B, depth), b.process(data, 25, B, depth), canon.process(data, 25, B, depth)
+        for x, y in zip(ra[:3], rb[:3]):
+            assert np.array_equal(x, y)
+        assert a.status() == b.status()
+        differs += int((ra[0] != rc[0]).sum())
+    assert differs > 0, "the contracted build must not be the canonical one"
