@@ -25,6 +25,7 @@ using namespace dspi;
 
 struct dspi_ctx {
     int flavor = 1;
+    bool fma = false;              // DSPI_FLOAT_CONTRACT_FMA: host design and kernels use the firmware build's fused multiply-adds
     uint32_t n_streams = 0, n_wg = 0;
     int device = DSPI_DEVICE_NONE;
     StateMap sm{};
@@ -310,7 +311,10 @@ extern "C" {
 int dspi_abi_version(void) { return DSPI_ABI_VERSION; }
 
 int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) {
+    const bool fma = (flavor & DSPI_FLOAT_CONTRACT_FMA) != 0;
+    flavor &= ~DSPI_FLOAT_CONTRACT_FMA;
     if (!out || (flavor != DSPI_FLAVOR_RP2040_Q28 && flavor != DSPI_FLAVOR_RP2350_F32) || n_streams == 0) return DSPI_E_INVAL;
+    if (fma && flavor != DSPI_FLAVOR_RP2350_F32) return DSPI_E_INVAL;      // the RP2040 has no FPU: nothing to contract
     dspi_ctx *c = new (std::nothrow) dspi_ctx();
     if (!c) return DSPI_E_NOMEM;
     c->flavor = flavor;
@@ -318,7 +322,8 @@ int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) 
     c->device = hip_device;
     c->sm = make_state_map(flavor);
     c->n_wg = (n_streams + (uint32_t)c->sm.row - 1) / (uint32_t)c->sm.row;
-    c->images.push_back(std::make_unique<Params>(flavor));
+    c->fma = fma;
+    c->images.push_back(std::make_unique<Params>(flavor, fma));
     c->image_refs.push_back(n_streams);
     c->stream_image.assign(n_streams, 0);
     *out = c;

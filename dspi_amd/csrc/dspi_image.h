@@ -45,6 +45,7 @@ enum ImageFlags : uint32_t {
     IF_CROSSFEED_ON = 1u << 3,       // !crossfeed_bypassed
     IF_SUB_ACTIVE = 1u << 4,         // core1_mode != CORE1_MODE_EQ_WORKER (usb_audio.c:782 vs :873)
     IF_ANY_DELAY = 1u << 5,          // any_delay_active
+    IF_FMA = 1u << 6,                // float contract of the firmware build: contracted multiply-adds (context-wide, dspi.h)
 };
 
 struct DevImage {

@@ -100,12 +100,20 @@ float db_to_linear_preset(float db) {   // flash_storage.c:302-306 (powf)
     return powf(10.0f, db / 20.0f);
 }
 
-float db_to_linear_bulk(float db) {     // bulk_params.c:49-56 (4-term Taylor, clamped)
+// The firmware's float contract (DSPI_FLOAT_CONTRACT_FMA): GNU C's default -ffp-contract=fast on the Cortex-M33 turns
+// a*b + c into one fused operation; which pairs is a property of GCC's GIMPLE pass (read off -fdump-tree-optimized of the
+// reference sources, oracle/Makefile FMA_FLAGS; oracle/orc_leaf.c carries the same list).  Every mad() in this file is one
+// of those statements: with the contract off it is the reference's expression with separate roundings, with it on the
+// fused form.  (-a)*b + c is c - a*b exactly, so FNMA/FMS need no form of their own.
+inline float mad(bool fma, float a, float b, float c) { return fma ? fmaf(a, b, c) : a * b + c; }
+
+float db_to_linear_bulk(float db, bool fma) {     // bulk_params.c:49-56 (4-term Taylor, clamped)
     if (db == 0.0f) return 1.0f;
     if (db < -60.0f) db = -60.0f;
     if (db > 20.0f) db = 20.0f;
     float x = db * 0.1151292546f;
-    float lin = 1.0f + x + x * x * 0.5f + x * x * x * 0.1666667f + x * x * x * x * 0.0416667f;
+    float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+    float lin = mad(fma, x4, 0.0416667f, mad(fma, x3, 0.1666667f, mad(fma, x2, 0.5f, 1.0f + x)));
     return (lin < 0.0f) ? 0.0f : lin;
 }
 
@@ -155,9 +163,10 @@ int32_t f2i_sat(float f) {
 // ============================================================================================
 // construction / boot
 // ============================================================================================
-Params::Params(int fl) {
+Params::Params(int fl, bool fma) {
     memset((void *)this, 0, sizeof(*this));
     flavor = fl;
+    fma_contract = fma && fl;            // the RP2040 has no FPU, hence nothing to contract
     StateMap m = make_state_map(fl);
     n_ch = m.n_ch; n_out = m.n_out; n_pairs = m.n_pairs; max_delay = m.max_delay;
     n_pins = fl ? 5 : 3;
@@ -245,16 +254,17 @@ void Params::design_band(Recipe &r, int ch, int b, float fs) {
                 case FT_HIGHSHELF: { float s = sqrtf(A); g = g * s; break; }
                 default: break;
             }
-            float a1 = 1.0f / (1.0f + g * (g + k));
+            const bool F = fma_contract;
+            float a1 = 1.0f / mad(F, g, g + k, 1.0f);
             float a2 = g * a1;
             float a3 = g * a2;
             float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
             switch (r.type) {
                 case FT_LOWPASS: m0 = 0.0f; m1 = 0.0f; m2 = 1.0f; break;
                 case FT_HIGHPASS: m0 = 1.0f; m1 = -k; m2 = -1.0f; break;
-                case FT_PEAKING: m0 = 1.0f; m1 = k * (A * A - 1.0f); m2 = 0.0f; break;
-                case FT_LOWSHELF: m0 = 1.0f; m1 = k * (A - 1.0f); m2 = A * A - 1.0f; break;
-                case FT_HIGHSHELF: m0 = A * A; m1 = k * (1.0f - A) * A; m2 = 1.0f - A * A; break;
+                case FT_PEAKING: m0 = 1.0f; m1 = k * mad(F, A, A, -1.0f); m2 = 0.0f; break;
+                case FT_LOWSHELF: m0 = 1.0f; m1 = k * (A - 1.0f); m2 = mad(F, A, A, -1.0f); break;
+                case FT_HIGHSHELF: m0 = A * A; m1 = k * (1.0f - A) * A; m2 = 1.0f - m0; break;      // A*A is shared: never fused
                 default: break;
             }
             q.sva1 = a1; q.sva2 = a2; q.sva3 = a3; q.svm0 = m0; q.svm1 = m1; q.svm2 = m2;
@@ -272,15 +282,23 @@ void Params::design_band(Recipe &r, int ch, int b, float fs) {
     switch (r.type) {
         case FT_LOWPASS: b0 = (1 - cs) / 2; b1 = 1 - cs; b2 = (1 - cs) / 2; a0 = 1 + alpha; a1 = -2 * cs; a2 = 1 - alpha; break;
         case FT_HIGHPASS: b0 = (1 + cs) / 2; b1 = -(1 + cs); b2 = (1 + cs) / 2; a0 = 1 + alpha; a1 = -2 * cs; a2 = 1 - alpha; break;
-        case FT_PEAKING: b0 = 1 + alpha * A; b1 = -2 * cs; b2 = 1 - alpha * A; a0 = 1 + alpha / A; a1 = -2 * cs; a2 = 1 - alpha / A; break;
-        case FT_LOWSHELF:
-            b0 = A * ((A + 1) - (A - 1) * cs + 2 * sqrtf(A) * alpha); b1 = 2 * A * ((A - 1) - (A + 1) * cs);
-            b2 = A * ((A + 1) - (A - 1) * cs - 2 * sqrtf(A) * alpha); a0 = (A + 1) + (A - 1) * cs + 2 * sqrtf(A) * alpha;
-            a1 = -2 * ((A - 1) + (A + 1) * cs); a2 = (A + 1) + (A - 1) * cs - 2 * sqrtf(A) * alpha; break;
-        case FT_HIGHSHELF:
-            b0 = A * ((A + 1) + (A - 1) * cs + 2 * sqrtf(A) * alpha); b1 = -2 * A * ((A - 1) + (A + 1) * cs);
-            b2 = A * ((A + 1) + (A - 1) * cs - 2 * sqrtf(A) * alpha); a0 = (A + 1) - (A - 1) * cs + 2 * sqrtf(A) * alpha;
-            a1 = 2 * ((A - 1) - (A + 1) * cs); a2 = (A + 1) - (A - 1) * cs - 2 * sqrtf(A) * alpha; break;
+        case FT_PEAKING:
+            b0 = mad(fma_contract, alpha, A, 1.0f); b1 = -2 * cs; b2 = mad(fma_contract, -alpha, A, 1.0f);
+            a0 = 1 + alpha / A; a1 = -2 * cs; a2 = 1 - alpha / A; break;
+        case FT_LOWSHELF: {      // (A+1) -/+ (A-1)*cs are the sums GCC keeps rounded; 2*sqrt(A)*alpha and (A+1)*cs are the fused products
+            const bool F = fma_contract;
+            const float Ap = A + 1, Am = A - 1, t = Am * cs, S2 = 2 * sqrtf(A), u = Ap - t, w = Ap + t;
+            b0 = A * mad(F, S2, alpha, u); b1 = 2 * A * mad(F, -Ap, cs, Am);
+            b2 = A * mad(F, -S2, alpha, u); a0 = mad(F, S2, alpha, w);
+            a1 = -2 * mad(F, Ap, cs, Am); a2 = mad(F, -S2, alpha, w); break;
+        }
+        case FT_HIGHSHELF: {
+            const bool F = fma_contract;
+            const float Ap = A + 1, Am = A - 1, t = Am * cs, S2 = 2 * sqrtf(A), u = Ap + t, w = Ap - t;
+            b0 = A * mad(F, S2, alpha, u); b1 = -2 * A * mad(F, Ap, cs, Am);
+            b2 = A * mad(F, -S2, alpha, u); a0 = mad(F, S2, alpha, w);
+            a1 = 2 * mad(F, -Ap, cs, Am); a2 = mad(F, -S2, alpha, w); break;
+        }
         default: break;
     }
     if (flavor) {
@@ -304,8 +322,7 @@ void Params::update_delay_samples(float fs) {   // dsp_pipeline.c:216-239
     for (int o = 0; o < n_out; o++) {
         float ms = channel_delays_ms[2 + o];
         if (o == n_out - 1) {
-            float align = (float)128 / fs * 1000.0f;    // SUB_ALIGN_SAMPLES, config.h:93-95
-            ms += align;
+            ms = mad(fma_contract, (float)128 / fs, 1000.0f, ms);    // ms += SUB_ALIGN_SAMPLES / fs * 1000, config.h:93-95
         }
         int32_t s = f2i_sat(ms * fs / 1000.0f);
         if (s > max_delay) s = max_delay;
@@ -349,24 +366,24 @@ void Params::init_default_filters() {   // dsp_pipeline.c:177-214
 
 // ---- loudness: ISO 226:2003 derived shelves (loudness.c:37-217) ----
 namespace {
-float iso226_spl(float Tf, float af, float Lu, float phon) {
+float iso226_spl(bool F, float Tf, float af, float Lu, float phon) {
     float B = 0.4f * powf(10.0f, (Tf + Lu) / 10.0f - 9.0f);
     float thr = powf(B, af);
-    float Af = 4.47e-3f * (powf(10.0f, 0.025f * phon) - 1.15f) + thr;
+    float Af = mad(F, 4.47e-3f, powf(10.0f, 0.025f * phon) - 1.15f, thr);
     if (Af < 1e-10f) Af = 1e-10f;
-    return (10.0f / af) * log10f(Af) - Lu + 94.0f;
+    return mad(F, 10.0f / af, log10f(Af), -Lu) + 94.0f;
 }
-float loud_comp_db(float Tf, float af, float Lu, float ref, float eff, float pct) {
+float loud_comp_db(bool F, float Tf, float af, float Lu, float ref, float eff, float pct) {
     if (eff >= ref) return 0.0f;
-    float sr = iso226_spl(Tf, af, Lu, ref);
-    float se = iso226_spl(Tf, af, Lu, eff);
+    float sr = iso226_spl(F, Tf, af, Lu, ref);
+    float se = iso226_spl(F, Tf, af, Lu, eff);
     float flat = eff - ref;
     float fc = se - sr;
     float comp = fc - flat;
     comp *= (pct / 100.0f);
     return comp;
 }
-void loud_shelf(int flavor, float freq, float Q, float gain_db, bool high, float fs, LoudCoeffs &o) {
+void loud_shelf(int flavor, bool F, float freq, float Q, float gain_db, bool high, float fs, LoudCoeffs &o) {
     if (fabsf(gain_db) < 0.01f) {
         o.bypass = true;
         for (auto &w : o.c) w.u = 0;
@@ -380,12 +397,12 @@ void loud_shelf(int flavor, float freq, float Q, float gain_db, bool high, float
         float rA = sqrtf(A);
         if (high) g = g * rA; else g = g / rA;
         float k = 1.0f / Q;
-        float a1 = 1.0f / (1.0f + g * (g + k));
+        float a1 = 1.0f / mad(F, g, g + k, 1.0f);
         float a2 = g * a1;
         float a3 = g * a2;
         o.c[0].f = a1; o.c[1].f = a2; o.c[2].f = a3;
-        if (high) { o.c[3].f = A * A; o.c[4].f = k * (1.0f - A) * A; o.c[5].f = 1.0f - A * A; }
-        else { o.c[3].f = 1.0f; o.c[4].f = k * (A - 1.0f); o.c[5].f = A * A - 1.0f; }
+        if (high) { o.c[3].f = A * A; o.c[4].f = k * (1.0f - A) * A; o.c[5].f = 1.0f - o.c[3].f; }
+        else { o.c[3].f = 1.0f; o.c[4].f = k * (A - 1.0f); o.c[5].f = mad(F, A, A, -1.0f); }
     } else {
         float omega = 2.0f * kPi * freq / fs;
         float sn = sinf(omega), cs = cosf(omega);
@@ -418,10 +435,10 @@ void Params::loudness_recompute(float fs) {   // loudness_recompute_table, loudn
         float eff = ref + vol_db;
         if (eff < 20.0f) eff = 20.0f;
         if (eff > ref) eff = ref;
-        float lo = loud_comp_db(44.0f, 0.432f, 80.4f, ref, eff, loudness_intensity_pct);
-        float hi = loud_comp_db(13.9f, 0.301f, 17.8f, ref, eff, loudness_intensity_pct);
-        loud_shelf(flavor, 200.0f, 0.707f, lo, false, fs, loud_table[v][0]);
-        loud_shelf(flavor, 6000.0f, 0.707f, hi, true, fs, loud_table[v][1]);
+        float lo = loud_comp_db(fma_contract, 44.0f, 0.432f, 80.4f, ref, eff, loudness_intensity_pct);
+        float hi = loud_comp_db(fma_contract, 13.9f, 0.301f, 17.8f, ref, eff, loudness_intensity_pct);
+        loud_shelf(flavor, fma_contract, 200.0f, 0.707f, lo, false, fs, loud_table[v][0]);
+        loud_shelf(flavor, fma_contract, 6000.0f, 0.707f, hi, true, fs, loud_table[v][1]);
     }
     loud_table_valid = true;
     dirty = true;
@@ -448,7 +465,7 @@ void Params::crossfeed_design(float fs) {   // crossfeed_compute_coefficients, c
     if (xfeed_cfg.itd_enabled) {
         float lp_delay = x / ((1.0f - x) * fs);
         float rem = 0.000220f - lp_delay;
-        if (rem > 0.0f) { float D = rem * fs; ap = (1.0f - D) / (1.0f + D); }
+        if (rem > 0.0f) ap = mad(fma_contract, -rem, fs, 1.0f) / mad(fma_contract, rem, fs, 1.0f);     // D = rem*fs: (1 - D) / (1 + D)
         else ap = 1.0f;
     } else ap = 1.0f;
     if (flavor) { xf_lp_a0.f = a0; xf_lp_b1.f = b1; xf_ap_a.f = ap; }
@@ -476,7 +493,7 @@ void Params::leveller_design(float fs) {   // leveller_compute_coefficients, lev
     if (amount < 0.0f) amount = 0.0f;
     if (amount > 100.0f) amount = 100.0f;
     float norm = amount / 100.0f;
-    lv_ratio = 1.0f + norm * 19.0f;
+    lv_ratio = mad(fma_contract, norm, 19.0f, 1.0f);
     float mg = lev_cfg.max_gain_db;
     if (mg < 0.0f) mg = 0.0f;
     if (mg > 35.0f) mg = 35.0f;
@@ -626,7 +643,7 @@ int Params::load_bulk(const void *blob, size_t len) {   // main.c:1126-1162 + bu
         if (in.header.payload_length < v2 || in.header.payload_length > sizeof(WireBulk)) return -4;
 
         auto set_preamp_all = [&](int i, float db) {
-            float lin = db_to_linear_bulk(db);
+            float lin = db_to_linear_bulk(db, fma_contract);
             preamp_db[i] = db; preamp_mul[i] = f2i_sat(lin * (float)(1 << 28)); preamp_linear[i] = lin;
         };
         for (int i = 0; i < 2; i++) set_preamp_all(i, in.global.preamp_gain_db);
@@ -640,7 +657,7 @@ int Params::load_bulk(const void *blob, size_t len) {   // main.c:1126-1162 + bu
         xfeed_pending = true;
         for (int i = 0; i < 3; i++) {
             legacy_gain_db[i] = in.legacy.gain_db[i];
-            float g = db_to_linear_bulk(in.legacy.gain_db[i]);
+            float g = db_to_linear_bulk(in.legacy.gain_db[i], fma_contract);
             legacy_gain_mul[i] = f2i_sat(g * 32768.0f); legacy_gain_linear[i] = g;
             legacy_mute[i] = in.legacy.mute[i] != 0;
         }
@@ -649,12 +666,12 @@ int Params::load_bulk(const void *blob, size_t len) {   // main.c:1126-1162 + bu
             for (int o = 0; o < n_out; o++) {
                 Crosspoint &c = xp[inp][o];
                 c.enabled = in.crosspoints[inp][o].enabled; c.phase_invert = in.crosspoints[inp][o].phase_invert;
-                c.gain_db = in.crosspoints[inp][o].gain_db; c.gain_linear = db_to_linear_bulk(c.gain_db);
+                c.gain_db = in.crosspoints[inp][o].gain_db; c.gain_linear = db_to_linear_bulk(c.gain_db, fma_contract);
             }
         for (int o = 0; o < n_out; o++) {
             OutputCh &oc = outs[o];
             oc.enabled = in.outputs[o].enabled; oc.mute = in.outputs[o].mute;
-            oc.gain_db = in.outputs[o].gain_db; oc.gain_linear = db_to_linear_bulk(oc.gain_db);
+            oc.gain_db = in.outputs[o].gain_db; oc.gain_linear = db_to_linear_bulk(oc.gain_db, fma_contract);
             oc.delay_ms = in.outputs[o].delay_ms;
             channel_delays_ms[2 + o] = in.outputs[o].delay_ms;      // overrides the delays[] entry (:262)
         }
@@ -1169,6 +1186,7 @@ void Params::build_image(DevImage &img) const {
     if (!crossfeed_bypassed) fl |= IF_CROSSFEED_ON;
     if (core1_mode != 2) fl |= IF_SUB_ACTIVE;
     if (any_delay_active) fl |= IF_ANY_DELAY;
+    if (fma_contract) fl |= IF_FMA;
     img.flags = fl;
     for (int ch = 0; ch < n_ch; ch++) if (channel_bypassed[ch]) img.ch_bypassed |= 1u << ch;
     img.fs_hz = freq;

@@ -81,10 +81,12 @@ def lib() -> C.CDLL:
 class Dspi:
     """`n_streams` DSPi devices on one GPU (device=None: host-only, parameter surface only)."""
 
-    def __init__(self, flavor: int, n_streams: int, device: int | None = 0):
+    def __init__(self, flavor: int, n_streams: int, device: int | None = 0, fma: bool = False):
+        """fma: the float flavour with the firmware build's FMA contraction (DSPI_FLOAT_CONTRACT_FMA, include/dspi.h)."""
         self.L = lib()
         self.h = C.c_void_p()
-        rc = self.L.dspi_create(C.byref(self.h), flavor, n_streams, -1 if device is None else device)
+        self.fma = fma
+        rc = self.L.dspi_create(C.byref(self.h), flavor | (0x100 if fma else 0), n_streams, -1 if device is None else device)
         if rc != 0:
             raise DspiError(rc, "dspi_create")
         self.flavor, self.n_streams = flavor, n_streams

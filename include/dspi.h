@@ -22,7 +22,8 @@
  * any number of streams (all streams start on one image = factory defaults).
  *
  * Numerics: DSPI_FLAVOR_RP2040_Q28 is bit-exact integer arithmetic; DSPI_FLAVOR_RP2350_F32
- * is IEEE binary32 with flush-to-zero, no contraction.  Both match oracle/ bit-for-bit
+ * is IEEE binary32 with flush-to-zero, either with no contraction or (DSPI_FLOAT_CONTRACT_FMA) with
+ * exactly the fused multiply-adds GCC gives the firmware.  All match oracle/ bit-for-bit
  * (tests/), the leveller's per-block log10f/powf being defined by include/dspi_detmath.h.
  *
  * Threading: a context is single-threaded.  Parameter calls take effect at the next
@@ -40,11 +41,21 @@
 extern "C" {
 #endif
 
-#define DSPI_ABI_VERSION 2   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode (additions only) */
+#define DSPI_ABI_VERSION 3   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
+                              * dspi_debug_taps (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
 #define DSPI_FLAVOR_RP2350_F32 1   /* 11 channels, 9 outputs, float, 4096-sample delay lines   */
+/* OR into the flavour of dspi_create: the float flavour AS THE FIRMWARE IS BUILT.  firmware/DSPi/CMakeLists.txt:6-11 sets only
+ * -O2/-O3, so GNU C's default -ffp-contract=fast applies and, the Cortex-M33 having vfma, GCC fuses a*b + c into one
+ * rounding wherever its contraction pass pairs them: biquad / SVF recurrences (dsp_pipeline.c:298-362), loudness shelves
+ * (usb_audio.c:697-712), matrix mix (:766), leveller envelope and smoother (leveller.c:165-166, :200), crossfeed
+ * (crossfeed.c:137-148) and the coefficient design functions.  Without the flag every multiply and add rounds on its own
+ * (the source read literally, -ffp-contract=off).  Both contracts are pinned bit-for-bit to the reference compiled the
+ * corresponding way (oracle/Makefile, tests/test_oracle_vs_fw.py); the fused one needs a third fewer vector instructions. */
+#define DSPI_FLOAT_CONTRACT_FMA 0x100
+#define DSPI_FLAVOR_RP2350_F32_FMA (DSPI_FLAVOR_RP2350_F32 | DSPI_FLOAT_CONTRACT_FMA)
 
 #define DSPI_ALL_STREAMS (-1)
 #define DSPI_DEVICE_NONE (-1)      /* host-only context: parameter surface works, dspi_process fails */

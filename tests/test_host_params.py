@@ -63,6 +63,16 @@ def check_against_oracle(d: Dspi, o: Oracle, flavor: int):
     assert [int(img["xf"][0]), int(img["xf"][1]), int(img["xf"][2])] == [int(xs[0]), int(xs[1]), int(xs[4])]
     row = o.scalar(0)
     loud = np.frombuffer(o.tap(1), dtype=np.uint8)
+    if row >= 0 and o.vendor_get(W.REQ["GET_LOUDNESS"], 0) == b"\x01":       # the selected row of the loudness table (loudness.h:10-23)
+        rec = 28 if flavor else 24
+        tab = loud.reshape(61, 2, rec)
+        for j in range(2):
+            words = tab[row, j, :rec - 4].view(np.uint32).tolist()
+            if tab[row, j, rec - 4]:
+                assert int(img["loud"][j]["kind"]) == 0
+            else:
+                assert int(img["loud"][j]["kind"]) == (5 if flavor else 1)
+                assert [int(v) for v in img["loud"][j]["c"]][:len(words)] == words, ("loudness stage", j)
     assert int(img["fs_hz"]) == o.scalar(10)
     assert bool(img["flags"] & 8) == (not o.scalar(4)) and bool(img["flags"] & 2) == (not o.scalar(5))     # crossfeed / leveller on
     assert bool(img["flags"] & 16) == (o.scalar(1) != 2) and bool(img["flags"] & 32) == bool(o.scalar(2))
@@ -77,16 +87,20 @@ def check_against_oracle(d: Dspi, o: Oracle, flavor: int):
     return img, row, loud
 
 
-@pytest.mark.parametrize("flavor", [1, 0])
-def test_boot_state_matches(product_lib, flavor):
-    d, o = Dspi(flavor, 3, device=None), Oracle(flavor)
+# (flavour, float contract): canonical float, float with the firmware build's FMA contraction, Q28
+FL = [(1, False), (1, True), (0, False)]
+
+
+@pytest.mark.parametrize("flavor,fma", FL)
+def test_boot_state_matches(product_lib, flavor, fma):
+    d, o = Dspi(flavor, 3, device=None, fma=fma), Oracle(flavor, fma=fma)
     check_against_oracle(d, o, flavor)
 
 
-@pytest.mark.parametrize("flavor", [1, 0])
+@pytest.mark.parametrize("flavor,fma", FL)
 @pytest.mark.parametrize("fs", [44100, 48000, 96000])
-def test_bulk_load_images(product_lib, flavor, fs):
-    d, o = Dspi(flavor, 2, device=None), Oracle(flavor)
+def test_bulk_load_images(product_lib, flavor, fma, fs):
+    d, o = Dspi(flavor, 2, device=None, fma=fma), Oracle(flavor, fma=fma)
     assert d.set_rate(fs) == 0 and o.set_rate(fs) == 0
     d.set_volume(-20 * 256); o.set_volume(-20 * 256)
     rng = np.random.default_rng(fs + flavor)
@@ -101,6 +115,8 @@ def test_bulk_load_images(product_lib, flavor, fs):
             blob["outputs"]["delay_ms"] = rng.uniform(0, 100, size=9).astype(np.float32)
             blob["preamp"]["preamp_db"] = rng.uniform(-30, 25, size=2).astype(np.float32)
             blob["leveller"]["amount"] = rng.uniform(-10, 120)
+            blob["global_"]["loudness_ref_spl"] = rng.uniform(60, 100); blob["global_"]["loudness_intensity_pct"] = rng.uniform(20, 180)
+            blob["crossfeed"]["custom_fc"] = rng.uniform(500, 2000); blob["crossfeed"]["custom_feed_db"] = rng.uniform(1, 14)
             blob["crossfeed"]["preset"] = trial % 4
             blob["header"]["format_version"] = [6, 6, 5, 4, 2][trial]
         assert d.load_bulk(blob) == 0 and o.load_bulk(blob) == 0
@@ -118,9 +134,9 @@ def test_bulk_error_codes(product_lib, flavor):
     assert d.load_bulk(blob.tobytes()[:-1]) == -4
 
 
-@pytest.mark.parametrize("flavor", [1, 0])
-def test_vendor_requests_match_oracle(product_lib, flavor):
-    d, o = Dspi(flavor, 2, device=None), Oracle(flavor)
+@pytest.mark.parametrize("flavor,fma", FL)
+def test_vendor_requests_match_oracle(product_lib, flavor, fma):
+    d, o = Dspi(flavor, 2, device=None, fma=fma), Oracle(flavor, fma=fma)
     d.set_rate(48000); o.set_rate(48000)
     R = W.REQ
     f = lambda v: struct.pack("<f", v)
@@ -157,9 +173,9 @@ def test_vendor_requests_match_oracle(product_lib, flavor):
     assert d.vendor_get(W.REQ["GET_ALL_PARAMS"], 0, 4096) == o.collect_bulk()
 
 
-@pytest.mark.parametrize("flavor", [1, 0])
-def test_preset_slot_roundtrip_and_legacy_versions(product_lib, flavor):
-    d, o = Dspi(flavor, 1, device=None), Oracle(flavor)
+@pytest.mark.parametrize("flavor,fma", FL)
+def test_preset_slot_roundtrip_and_legacy_versions(product_lib, flavor, fma):
+    d, o = Dspi(flavor, 1, device=None, fma=fma), Oracle(flavor, fma=fma)
     blob = WL.full_chain_blob(flavor)
     assert d.load_bulk(blob) == 0 and o.load_bulk(blob) == 0
     img = d.save_slot(7)
