@@ -561,6 +561,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.state = c->d_state; a.dlines = c->d_dlines; a.ring = c->d_ring;
     a.n_streams = c->n_streams; a.n_blocks = n_blocks; a.block_len = block_len; a.bit_depth = (uint32_t)bit_depth;
     a.tiled_out = tiled ? 1u : 0u;
+    a.fma = c->fma ? 1u : 0u;
     if (dev) {
         a.pcm = pcm_in; a.pairs = out->pairs; a.sub = out->sub; a.peaks = out->peaks;
     } else {

@@ -57,31 +57,39 @@ __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(fl
 __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 #include "dspi_bandloops.inc"
+#include "dspi_bandloops_fma.inc"
+
+// a*b + c under the context's float contract (include/dspi.h DSPI_FLOAT_CONTRACT_FMA): FMA = one fused rounding, as GCC
+// contracts the firmware; otherwise the two roundings of the source read literally (the file is built -ffp-contract=off)
+template <bool FMA> __device__ __forceinline__ float mad1(float a, float b, float c) {
+    if (FMA) return __builtin_fmaf(a, b, c);
+    return a * b + c;
+}
 
 // ------------------------------------------------------------------------------------------
 // One band over one chunk, specialised on the output form so that the sample loop is branch-free
 // straight-line code (the reference specialises the same way: dsp_pipeline.c:298-343).
-template <bool TAIL, uint32_t KIND>
+template <bool TAIL, uint32_t KIND, bool FMA = false>
 __device__ __forceinline__ void band_loop_f32(float (&x)[T], int n, float &s1, float &s2, float c0, float c1, float c2, float c3, float c4, float c5) {
 #pragma unroll
     for (int i = 0; i < T; ++i) {
         if (TAIL && i >= n) break;
         const float in = x[i];
         if (KIND == K_BIQUAD) {           // dsp_pipeline.c:347-362
-            float y = c0 * in + s1;
-            s1 = c1 * in - c3 * y + s2;
-            s2 = c2 * in - c4 * y;
+            float y = mad1<FMA>(c0, in, s1);
+            s1 = mad1<FMA>(c1, in, -(c3 * y)) + s2;
+            s2 = mad1<FMA>(c2, in, -(c4 * y));
             x[i] = y;
         } else {                          // Cytomic SVF core (s1 = ic1eq, s2 = ic2eq)
             float v3 = in - s2;
-            float v1 = c0 * s1 + c1 * v3;
-            float v2 = s2 + c1 * s1 + c2 * v3;
-            s1 = 2.0f * v1 - s1;
-            s2 = 2.0f * v2 - s2;
+            float v1 = mad1<FMA>(c0, s1, c1 * v3);
+            float v2 = mad1<FMA>(c2, v3, mad1<FMA>(c1, s1, s2));
+            s1 = mad1<FMA>(2.0f, v1, -s1);
+            s2 = mad1<FMA>(2.0f, v2, -s2);
             if (KIND == K_SVF_LP) x[i] = v2;
-            else if (KIND == K_SVF_HP) x[i] = in + c3 * v1 - v2;
-            else if (KIND == K_SVF_PK) x[i] = in + c3 * v1;
-            else x[i] = c3 * in + c4 * v1 + c5 * v2;
+            else if (KIND == K_SVF_HP) x[i] = mad1<FMA>(c3, v1, in) - v2;
+            else if (KIND == K_SVF_PK) x[i] = mad1<FMA>(c3, v1, in);
+            else x[i] = mad1<FMA>(c5, v2, mad1<FMA>(c3, in, c4 * v1));
         }
     }
 }
@@ -157,7 +165,7 @@ __device__ __forceinline__ void run_bands(float (&x)[T], int n, BandPtr bands, f
 // Per-lane parameters (the one-stream float kernel): every lane reads ITS stream's DevImage, so coefficients are vector
 // loads into VGPRs and the band kind is a per-lane value — the switch below is ordinary SIMT divergence (lanes of one kind
 // run together, kinds one after the other).  Same arithmetic, same order.
-template <bool TAIL, int NB, bool SHELF_ONLY = false>
+template <bool TAIL, int NB, bool SHELF_ONLY = false, bool FMA = false>
 __device__ __forceinline__ void run_bands(float (&x)[T], int n, const DevBand *bands, float *__restrict__ st) {
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
     // band b+1's 32-byte descriptor (two 16-byte vector loads per lane) and state pair are requested before band b runs
@@ -174,16 +182,19 @@ __device__ __forceinline__ void run_bands(float (&x)[T], int n, const DevBand *b
         if ((!TAIL || n == T) && __all(kind == k0)) {
             // the usual case: all lanes of the wave use the same form at this band index (presets of one product family):
             // the hand-written loop, with per-lane coefficients in VGPRs
-            if (SHELF_ONLY) band16v_shelf(x, s1, s2, k0, c0, c1, c2, c3, c4, c5);
+            if (FMA) {
+                if (SHELF_ONLY) band16vf_shelf(x, s1, s2, k0, c0, c1, c2, c3, c4, c5);
+                else band16vf_any(x, s1, s2, k0, c0, c1, c2, c3, c4, c5);
+            } else if (SHELF_ONLY) band16v_shelf(x, s1, s2, k0, c0, c1, c2, c3, c4, c5);
             else band16v_any(x, s1, s2, k0, c0, c1, c2, c3, c4, c5);
         } else if (kind != K_BYPASS) {
-            if (SHELF_ONLY) band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5);
+            if (SHELF_ONLY) band_loop_f32<TAIL, K_SVF_SHELF, FMA>(x, n, s1, s2, c0, c1, c2, c3, c4, c5);
             else switch (kind) {
-                case K_BIQUAD: band_loop_f32<TAIL, K_BIQUAD>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-                case K_SVF_LP: band_loop_f32<TAIL, K_SVF_LP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-                case K_SVF_HP: band_loop_f32<TAIL, K_SVF_HP>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-                case K_SVF_PK: band_loop_f32<TAIL, K_SVF_PK>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
-                default: band_loop_f32<TAIL, K_SVF_SHELF>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_BIQUAD: band_loop_f32<TAIL, K_BIQUAD, FMA>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_LP: band_loop_f32<TAIL, K_SVF_LP, FMA>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_HP: band_loop_f32<TAIL, K_SVF_HP, FMA>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_PK: band_loop_f32<TAIL, K_SVF_PK, FMA>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                default: band_loop_f32<TAIL, K_SVF_SHELF, FMA>(x, n, s1, s2, c0, c1, c2, c3, c4, c5); break;
             }
         }
         st[b * 2 * kLanes] = s1;
@@ -204,7 +215,7 @@ __device__ __forceinline__ float gain_computer(float x_db, float thr, float rati
 }
 
 // per-packet gain decision, leveller.c:174-206 (float) == :304-332 (Q28); libm -> dspi_detmath.h
-template <class IMG>
+template <bool FMA = false, class IMG>
 __device__ __forceinline__ float leveller_block_gain(IMG img, float &gsm_db, float rms_sq, uint32_t count) {
     float rms_db = 10.0f * dspi_det_log10f(rms_sq + 1e-30f);
     float gc;
@@ -216,7 +227,7 @@ __device__ __forceinline__ float leveller_block_gain(IMG img, float &gsm_db, flo
     }
     float a_s = (gc < gsm_db) ? img->lv_alpha_attack : img->lv_alpha_release;
     float alpha = dspi_det_powf(a_s, (float)count);
-    gsm_db = alpha * gsm_db + (1.0f - alpha) * gc;
+    gsm_db = mad1<FMA>(alpha, gsm_db, (1.0f - alpha) * gc);      // leveller.c:200
     return dspi_det_powf(10.0f, gsm_db / 20.0f);
 }
 
@@ -270,7 +281,7 @@ struct MasterF32 {
 // whose neighbours carry different presets.  Consequences: every `img->` read is a vector load, every parameter test is
 // SIMT divergence, and the step schedule cannot depend on a lane's flags — so every lane's samples travel through the ring
 // (one packet late), whether its leveller is on or not; a leveller that is off just copies them through.
-template <bool TAIL>
+template <bool TAIL, bool FMA>
 __device__ __forceinline__ void master_step_f32(const KArgs &a, const DevImage *img, const StateMap &sm, const Geo &g,
                                                 MasterF32 &m, float *__restrict__ lds_state, float *__restrict__ xch_base,
                                                 uint32_t wg, uint32_t lane, uint32_t col, uint32_t stream, bool active,
@@ -371,12 +382,12 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, const DevImage *
             }
         }
         // ---- loudness shelves (usb_audio.c:688-718) ----
-        run_bands<TAIL, 2, true>(xl, n, &img->loud[0], lds_state + (sm.loud + 0) * kLanes + lane);
-        run_bands<TAIL, 2, true>(xr, n, &img->loud[0], lds_state + (sm.loud + 4) * kLanes + lane);
+        run_bands<TAIL, 2, true, FMA>(xl, n, &img->loud[0], lds_state + (sm.loud + 0) * kLanes + lane);
+        run_bands<TAIL, 2, true, FMA>(xr, n, &img->loud[0], lds_state + (sm.loud + 4) * kLanes + lane);
         // ---- PASS 2: master EQ (usb_audio.c:721-728) ----
         if (!(flags & IF_BYPASS_MASTER_EQ)) {
-            if (!(img->ch_bypassed & 1u)) run_bands<TAIL, kBands>(xl, n, &img->eq[0][0], lds_state + (sm.eq + 0) * kLanes + lane);
-            if (!(img->ch_bypassed & 2u)) run_bands<TAIL, kBands>(xr, n, &img->eq[1][0], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
+            if (!(img->ch_bypassed & 1u)) run_bands<TAIL, kBands, false, FMA>(xl, n, &img->eq[0][0], lds_state + (sm.eq + 0) * kLanes + lane);
+            if (!(img->ch_bypassed & 2u)) run_bands<TAIL, kBands, false, FMA>(xr, n, &img->eq[1][0], lds_state + (sm.eq + kBands * 2) * kLanes + lane);
         }
         {
             // ---- leveller pass 1: RMS envelopes (leveller.c:155-172); every lane parks its samples in the ring ----
@@ -388,8 +399,8 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, const DevImage *
             for (int i = 0; i < T; ++i) {
                 if (TAIL && i >= n) break;
                 if (lev_on) {
-                    m.env_l = ar * m.env_l + nar * (xl[i] * xl[i]);
-                    m.env_r = ar * m.env_r + nar * (xr[i] * xr[i]);
+                    m.env_l = mad1<FMA>(ar, m.env_l, nar * (xl[i] * xl[i]));
+                    m.env_r = mad1<FMA>(ar, m.env_r, nar * (xr[i] * xr[i]));
                 }
                 if (active) {
                     if (flat) { wl[i * ROW] = as_u(xl[i]); wl[(kRingLen + i) * ROW] = as_u(xr[i]); }
@@ -405,7 +416,7 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, const DevImage *
                     if (m.env_l < 1e-30f) m.env_l = 0.0f;
                     if (m.env_r < 1e-30f) m.env_r = 0.0f;
                     float rms_sq = (m.env_l > m.env_r) ? m.env_l : m.env_r;
-                    float gn = leveller_block_gain(img, m.gsm_db, rms_sq, g.B);
+                    float gn = leveller_block_gain<FMA>(img, m.gsm_db, rms_sq, g.B);
                     m.g_prev = m.g_cur;
                     m.g_cur = gn;
                 }
@@ -451,13 +462,13 @@ __device__ __forceinline__ void master_step_f32(const KArgs &a, const DevImage *
         float al = fabsf(ml); if (al > m.pk_l) m.pk_l = al;
         float ar = fabsf(mr); if (ar > m.pk_r) m.pk_r = ar;
         if (xf) {
-            float lpl = a0 * ml + b1 * m.lpL;
-            float lpr = a0 * mr + b1 * m.lpR;
+            float lpl = mad1<FMA>(a0, ml, b1 * m.lpL);
+            float lpr = mad1<FMA>(a0, mr, b1 * m.lpR);
             m.lpL = lpl; m.lpR = lpr;
-            float apl = apa * lpl + m.apL;
-            m.apL = lpl - apa * apl;
-            float apr = apa * lpr + m.apR;
-            m.apR = lpr - apa * apr;
+            float apl = mad1<FMA>(apa, lpl, m.apL);
+            m.apL = mad1<FMA>(-apa, apl, lpl);
+            float apr = mad1<FMA>(apa, lpr, m.apR);
+            m.apR = mad1<FMA>(-apa, apr, lpr);
             float dl = (ml - lpl) + apr;
             float dr = (mr - lpr) + apl;
             ml = dl; mr = dr;
@@ -492,7 +503,7 @@ struct OutF32 {
     uint32_t clip;
 };
 
-template <bool TAIL>
+template <bool TAIL, bool FMA>
 __device__ __forceinline__ void output_item_f32(const KArgs &a, const DevImage *img, const StateMap &sm, const Geo &g,
                                                 OutF32 &s, float *__restrict__ lds_state, float *__restrict__ lds_pk, const float *__restrict__ xch_base,
                                                 uint32_t wg, uint32_t lane, uint32_t col, uint32_t stream, bool active,
@@ -570,7 +581,7 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, const DevImage *
         const float gl = img->mix[0][o].f, gr = img->mix[1][o].f;
         if (enabled && gl != 0.0f && gr != 0.0f) {
 #pragma unroll
-            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = L[i] * gl + R[i] * gr; }
+            for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = mad1<FMA>(L[i], gl, R[i] * gr); }
         } else if (enabled && gl != 0.0f) {
 #pragma unroll
             for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; x[i] = L[i] * gl; }
@@ -586,7 +597,7 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, const DevImage *
             if (enabled) {
                 const int ch = 2 + o;
                 if (!muted && !((img->ch_bypassed >> ch) & 1u))
-                    run_bands<TAIL, kBands>(x, n, &img->eq[ch][0], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
+                    run_bands<TAIL, kBands, false, FMA>(x, n, &img->eq[ch][0], lds_state + (sm.eq + ch * kBands * 2) * kLanes + lane);
                 float gain = muted ? 0.0f : img->out_gain_lin[o] * s.vmm;
 #pragma unroll
                 for (int i = 0; i < T; ++i) {
@@ -1134,7 +1145,7 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const S
 // the one-stream-per-lane kernel (Q28 flavour; float flavour: lanes whose two streams differ in image)
 // ==========================================================================================
 // PL (Q28 only; the float instantiation is always per-lane): per-lane parameter images for rows with several presets
-template <int FLAVOR, bool TAIL, bool PL = false>
+template <int FLAVOR, bool TAIL, bool PL = false, bool FMA = false>
 __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     constexpr StateMap sm = make_state_map(FLAVOR);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1309,9 +1320,9 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
                 // (ragged packets: full chunks take the exit-free instantiation; lag is a whole packet, so both halves of a
                 // step sit at the same chunk of their packets)
                 if (TAIL && ((do_p1 ? c1 : cq) + 1) * T > g.B)
-                    master_step_f32<true>(a, img_l, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
+                    master_step_f32<true, FMA>(a, img_l, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
                 else
-                    master_step_f32<false>(a, img_l, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
+                    master_step_f32<false, FMA>(a, img_l, sm, g, m, lds_state, xch, wg, lane, col, stream, active, do_p1, k1, c1, do_item, kq, cq, q);
             }
             if (do_p1) { if (++c1 == g.cpb) { c1 = 0; ++k1; } }
             if (do_item) { if (++cq == g.cpb) { cq = 0; ++kq; } }
@@ -1346,9 +1357,9 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
                 if (TAIL && (cq + 1) * T > g.B)
-                    output_item_f32<true>(a, img_l, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
+                    output_item_f32<true, FMA>(a, img_l, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
                 else
-                    output_item_f32<false>(a, img_l, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
+                    output_item_f32<false, FMA>(a, img_l, sm, g, s, lds_state, lds_pk, xch, wg, lane, col, stream, active, o_first, o_count, kq, cq, q);
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
             WT_BEFORE_BARRIER;
@@ -1440,7 +1451,7 @@ size_t chain_lds_bytes(int flavor, int packed) {
 
 constexpr int kMaxDevices = 65;      // slot 64: any device index beyond (attribute set on every launch)
 
-template <int FLAVOR, bool PL>
+template <int FLAVOR, bool PL, bool FMA = false>
 static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(FLAVOR, 0);
     // the dynamic-LDS limit is a per-device function attribute: remember it per device (contexts on several GPUs may
@@ -1449,50 +1460,52 @@ static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
     if (!attr_set[dev] || dev == kMaxDevices - 1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, false, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, true, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, false, PL, FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<FLAVOR, true, PL, FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<FLAVOR, true, PL>), dim3(n_items), dim3(256), lds, stream, args);
-    else hipLaunchKernelGGL((chain_kernel<FLAVOR, false, PL>), dim3(n_items), dim3(256), lds, stream, args);
+    if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<FLAVOR, true, PL, FMA>), dim3(n_items), dim3(256), lds, stream, args);
+    else hipLaunchKernelGGL((chain_kernel<FLAVOR, false, PL, FMA>), dim3(n_items), dim3(256), lds, stream, args);
     return hipGetLastError();
 }
 
-template <bool TAIL, bool LEV, bool PCM24, bool TILED>
+template <bool TAIL, bool LEV, bool PCM24, bool TILED, bool FMA>
 static hipError_t launch_chain_pk_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(1, 1);
     static bool attr_set[kMaxDevices] = {};      // per device, see launch_chain_t
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
     if (!attr_set[dev] || dev == kMaxDevices - 1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24, TILED>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
+    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
     return hipGetLastError();
 }
 
-template <bool TAIL, bool LEV>
+template <bool TAIL, bool LEV, bool FMA>
 static hipError_t launch_chain_pk_2(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const bool p24 = args.bit_depth == 24, tl = args.tiled_out != 0;
-    if (p24) return tl ? launch_chain_pk_t<TAIL, LEV, true, true>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, true, false>(args, n_items, stream);
-    return tl ? launch_chain_pk_t<TAIL, LEV, false, true>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, false, false>(args, n_items, stream);
+    if (p24) return tl ? launch_chain_pk_t<TAIL, LEV, true, true, FMA>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, true, false, FMA>(args, n_items, stream);
+    return tl ? launch_chain_pk_t<TAIL, LEV, false, true, FMA>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, false, false, FMA>(args, n_items, stream);
 }
 
+template <bool FMA>
 static hipError_t launch_chain_pk(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream) {
     const bool tail = (args.block_len % T) != 0;
-    if (tail) return leveller_on ? launch_chain_pk_2<true, true>(args, n_items, stream) : launch_chain_pk_2<true, false>(args, n_items, stream);
-    return leveller_on ? launch_chain_pk_2<false, true>(args, n_items, stream) : launch_chain_pk_2<false, false>(args, n_items, stream);
+    if (tail) return leveller_on ? launch_chain_pk_2<true, true, FMA>(args, n_items, stream) : launch_chain_pk_2<true, false, FMA>(args, n_items, stream);
+    return leveller_on ? launch_chain_pk_2<false, true, FMA>(args, n_items, stream) : launch_chain_pk_2<false, false, FMA>(args, n_items, stream);
 }
 
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream) {
     // packed: 0 = one stream per lane, workgroup-uniform image (Q28) | 1 = packed float kernel | 2 = one stream per lane,
     // per-lane images (float always; Q28 rows with several presets)
     if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
-    if (packed != 1) return launch_chain_t<1, false>(args, n_items, stream);
-    return launch_chain_pk(args, leveller_on, n_items, stream);
+    // float: the context's contract (DSPI_FLOAT_CONTRACT_FMA) picks the kernel family
+    if (packed != 1) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
+    return args.fma ? launch_chain_pk<true>(args, leveller_on, n_items, stream) : launch_chain_pk<false>(args, leveller_on, n_items, stream);
 }
 
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,

@@ -85,6 +85,8 @@ class Dspi:
         """fma: the float flavour with the firmware build's FMA contraction (DSPI_FLOAT_CONTRACT_FMA, include/dspi.h)."""
         self.L = lib()
         self.h = C.c_void_p()
+        fma = bool(fma or getattr(flavor, "fma", False))      # tests pass wire.F32_FMA: the int 1 carrying the contract
+        flavor = int(flavor)
         self.fma = fma
         rc = self.L.dspi_create(C.byref(self.h), flavor | (0x100 if fma else 0), n_streams, -1 if device is None else device)
         if rc != 0:

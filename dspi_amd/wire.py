@@ -132,6 +132,19 @@ REQ = dict(
 )
 
 
+class FlavorFma(int):
+    """The float flavour with the firmware build's FMA contraction (include/dspi.h DSPI_FLOAT_CONTRACT_FMA): behaves as the
+    int 1 everywhere (blob builders, channel counts), and host.Dspi / tests' Oracle read the contract off `.fma`."""
+    fma = True
+
+    def __repr__(self):
+        return "1fma"
+    __str__ = __repr__
+
+
+F32_FMA = FlavorFma(1)
+
+
 def new_bulk(flavor: int) -> np.ndarray:
     """A zeroed V6 blob with a valid header for `flavor` (all bands FLAT-typed at 1 kHz/0.707 like
     dsp_init_default_filters, outputs disabled, unity gains, leveller/crossfeed/loudness off)."""

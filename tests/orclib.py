@@ -107,6 +107,8 @@ class Oracle:
         fma: the firmware's float contract (contraction on).  The standalone build switches at run time
         (orc_set_fma_mode, explicit fmaf in the pattern GCC produces); the reference builds are separate libraries.
         flash: (fw only) boot from this 48 KB preset area instead of an erased flash."""
+        fma = bool(fma or getattr(flavor, "fma", False))      # wire.F32_FMA: the int 1 carrying the contract
+        flavor = int(flavor)
         self.lib = load(flavor, ref, fma if ref else False)
         self.flavor = flavor
         self.fma = fma

@@ -62,7 +62,7 @@ def random_blob(rng, flavor, fs):
     return b
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 12))))      # more seeds: DSPI_FUZZ_SEEDS=200 pytest ...
 def test_random_presets(flavor, seed):
     from test_gpu_parity import compare
@@ -113,7 +113,7 @@ def random_request(rng, flavor, fs):
     return R["SET_MASTER_VOLUME"], 0, f(rng.choice([0.0, -128.0, rng.uniform(-70, 0)]))
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 6))))
 def test_random_request_sequences(flavor, seed):
     """Random vendor SET requests between launches — to every stream or to one — with their side effects on audio state
@@ -168,7 +168,7 @@ def test_random_request_sequences(flavor, seed):
     d.close()
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 6))))
 def test_output_pointer_and_layout_combinations(flavor, seed):
     """dspi_process with any subset of {pairs, sub, peaks} requested, in either layout, 16- or 24-bit input, must hand back
@@ -201,7 +201,7 @@ def test_output_pointer_and_layout_combinations(flavor, seed):
                     assert np.array_equal(a_, b_), f"{name} differ with {kw}, launch {c}"
 
 
-@pytest.mark.parametrize("flavor", (1, 0))
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 4))))
 def test_random_preset_per_stream(flavor, seed):
     """Every stream loads its own random blob: band kinds, flags, delays and leveller / crossfeed / loudness settings all

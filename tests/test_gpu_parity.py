@@ -17,7 +17,8 @@ from dspi_amd.host import Dspi
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no GPU")]
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-FLAVORS_WITH_KERNEL = (1, 0)
+# float canonical, float with the firmware build's FMA contraction (every scenario runs both ways), Q28
+FLAVORS_WITH_KERNEL = (1, W.F32_FMA, 0)
 
 
 def oracle_run(flavor, fs, vol, blob, data, blocks, B, depth, setup=None):

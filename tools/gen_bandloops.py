@@ -21,12 +21,22 @@ producer (tools/probe/probe4), so independent work of the following samples is i
 import os
 
 T = 16
+FMA = False     # which float contract the lists below describe; main() emits both (see ops())
 
 # ---------------------------------------------------------------------------------------------------------
 # operation lists: (op, dst, a, b) with op in mul/add/sub/mov; operands: 'x' (sample, in place), 's1','s2',
 # 'c0'..'c5', temps 't0'..'t3'
 # ---------------------------------------------------------------------------------------------------------
 def ops(kind):
+    """Canonical contract: one instruction per reference operation.  FMA contract (the firmware as built, GCC's
+    -ffp-contract=fast on the Cortex-M33): the fused multiply-adds of GCC's GIMPLE for dsp_pipeline.c:298-362, read off
+    -fdump-tree-optimized (oracle/Makefile FMA_FLAGS; oracle/orc_leaf.c orc_dsp_process_channel_block is the same list):
+        biquad  y = fma(b0,in,s1); s1 = fma(b1,in,-(a1*y)) + s2; s2 = fma(b2,in,-(a2*y))
+        SVF     v3 = in - ic2; v1 = fma(a1,ic1,a2*v3); v2 = fma(a3,v3,fma(a2,ic1,ic2)); ic = fma(2,v,-ic)
+                LP v2 | HP fma(m1,v1,in) - v2 | PK fma(m1,v1,in) | shelf fma(m2,v2,fma(m0,in,m1*v1))
+    ops are (op, dst, a, b[, c]); 'fma' is dst = a*b + c, a leading '-' on c negates it."""
+    if FMA:
+        return ops_fma(kind)
     if kind == 'BQ':   # TDF2 biquad
         return [('mul', 't0', 'c0', 'x'),      # b0*in
                 ('mul', 't1', 'c1', 'x'),      # b1*in
@@ -60,19 +70,61 @@ def ops(kind):
     raise ValueError(kind)
 
 
+def ops_fma(kind):
+    if kind == 'BQ':   # the input must outlive y (b1*in and b2*in are fused with products of y): y lives in t3, one copy at the end
+        return [('fma', 't3', 'c0', 'x', 's1'),     # y = b0*in + s1
+                ('mul', 't0', 'c3', 't3'),          # a1*y
+                ('fma', 't1', 'c1', 'x', '-t0'),    # b1*in - a1*y
+                ('add', 's1', 't1', 's2'),          # ... + s2
+                ('mul', 't2', 'c4', 't3'),          # a2*y
+                ('fma', 's2', 'c2', 'x', '-t2'),    # b2*in - a2*y
+                ('mov', 'x', 't3', None)]
+    v2 = 'x' if kind == 'LP' else 't2'
+    core = [('sub', 't0', 'x', 's2'),               # v3 = in - ic2eq
+            ('mul', 't2', 'c1', 't0'),              # a2*v3
+            ('fma', 't1', 'c0', 's1', 't2'),        # v1 = a1*ic1eq + a2*v3
+            ('fma', 't2', 'c1', 's1', 's2'),        # a2*ic1eq + ic2eq
+            ('fma', v2, 'c2', 't0', 't2'),          # v2 = a3*v3 + (...)
+            ('fma2', 's1', 't1', 's1'),             # ic1eq = 2 v1 - ic1eq
+            ('fma2', 's2', v2, 's2')]               # ic2eq = 2 v2 - ic2eq
+    if kind == 'LP':
+        return core
+    if kind == 'HP':
+        return core + [('fma', 'x', 'c3', 't1', 'x'), ('sub', 'x', 'x', 't2')]
+    if kind == 'PK':
+        return core + [('fma', 'x', 'c3', 't1', 'x')]
+    if kind == 'SH':
+        return core + [('mul', 't0', 'c4', 't1'), ('fma', 'x', 'c3', 'x', 't0'), ('fma', 'x', 'c5', 't2', 'x')]
+    raise ValueError(kind)
+
+
+def split(o):
+    """(op, d, a, b, c, negc) of an ops() entry"""
+    op, d, a, b = o[:4]
+    c = o[4] if len(o) > 4 else None
+    neg = bool(c) and c[0] == '-'
+    return op, d, a, b, (c[1:] if neg else c), neg
+
+
 # ---------------------------------------------------------------------------------------------------------
 # scalar family: straight program order (a dependent non-packed op issues back to back)
 # ---------------------------------------------------------------------------------------------------------
-def scalar_line(op, d, a, b, i, tset=0):
+def scalar_line(o, i):
+    op, d, a, b, c, neg = split(o)
+
     def r(n):
         return '%%[x%d]' % i if n == 'x' else '%%[%s]' % n
     if op == 'fma2':
         return "v_fma_f32 %s, 2.0, %s, -%s" % (r(d), r(a), r(b))
+    if op == 'fma':
+        return "v_fma_f32 %s, %s, %s, %s%s" % (r(d), r(a), r(b), '-' if neg else '', r(c))
+    if op == 'mov':
+        return "v_mov_b32 %s, %s" % (r(d), r(a))
     return "v_%s_f32 %s, %s, %s" % (op, r(d), r(a), r(b))
 
 
 def block_scalar(kind):
-    return [scalar_line(*o, i) for i in range(T) for o in ops(kind)]
+    return [scalar_line(o, i) for i in range(T) for o in ops(kind)]
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -93,13 +145,22 @@ def pk_operand(n, i):
     return '%%[c%d%d]' % (c & ~1, c | 1), ('lo' if c % 2 == 0 else 'hi')
 
 
-def pk_line(op, d, a, b, i):
-    dn, _ = pk_operand(d, i)
-    an, asel = pk_operand(a, i)
-    bn, bsel = pk_operand(b, i)
-    assert not bsel, "coefficients are always the first source"
+def pk_text(op, dn, an, asel, bn, cn, neg):
+    """One VOP3P instruction.  A coefficient is always the first source: op_sel picks its half of the SGPR pair and
+    broadcasts it to both streams (lo: op_sel 0 / op_sel_hi 0, hi: op_sel 1 / op_sel_hi 1)."""
     if op == 'fma2':
         return "v_pk_fma_f32 %s, %%[two], %s, %s neg_lo:[0,0,1] neg_hi:[0,0,1]" % (dn, an, bn)
+    if op == 'mov':
+        return "v_pk_mov_b32 %s, %s, %s op_sel:[0,1]" % (dn, an, an)
+    if op == 'fma':
+        mods = ''
+        if asel == 'lo':
+            mods += ' op_sel_hi:[0,1,1]'
+        elif asel == 'hi':
+            mods += ' op_sel:[1,0,0]'
+        if neg:
+            mods += ' neg_lo:[0,0,1] neg_hi:[0,0,1]'
+        return "v_pk_fma_f32 %s, %s, %s, %s%s" % (dn, an, bn, cn, mods)
     mods = ''
     if asel == 'lo':
         mods += ' op_sel_hi:[0,1]'
@@ -108,6 +169,22 @@ def pk_line(op, d, a, b, i):
     if op == 'sub':
         mods += ' neg_lo:[0,1] neg_hi:[0,1]'
     return "v_pk_%s_f32 %s, %s, %s%s" % ('mul' if op == 'mul' else 'add', dn, an, bn, mods)
+
+
+def pk_line(o, i, operand=None):
+    operand = operand or (lambda n: pk_operand(n, i))
+    op, d, a, b, c, neg = split(o)
+    dn, _ = operand(d)
+    an, asel = operand(a)
+    bn, bsel = operand(b) if b else (None, '')
+    cn, csel = operand(c) if c else (None, '')
+    assert not bsel and not csel, "coefficients are always the first source"
+    return pk_text(op, dn, an, asel, bn, cn, neg)
+
+
+def reads(o, phys):
+    op, d, a, b, c, neg = split(o)
+    return [phys(n) for n in (a, b, c) if n]
 
 
 def schedule(inst, lat_slots):
@@ -166,14 +243,14 @@ def block_pk(kind):
     # instances with concrete register names for hazard analysis
     inst = []
     for i in range(T):
-        for (op, d, a, b) in ops(kind):
+        for o in ops(kind):
             def phys(n):
                 if n == 'x':
                     return 'x%d' % i
                 if n[0] == 't':
                     return 't%d_%s' % (i % NTSETS, n[1])
                 return n
-            inst.append(dict(text=pk_line(op, d, a, b, i), w=phys(d), r=[phys(a), phys(b)]))
+            inst.append(dict(text=pk_line(o, i), w=phys(o[1]), r=reads(o, phys)))
     return schedule(inst, LAT_SLOTS)[0]
 
 
@@ -197,28 +274,15 @@ def pk_operand2(n, i, ch):
     return '%%[%s%d%d]' % (ch, c & ~1, c | 1), ('lo' if c % 2 == 0 else 'hi')
 
 
-def pk_line2(op, d, a, b, i, ch):
-    dn, _ = pk_operand2(d, i, ch)
-    an, asel = pk_operand2(a, i, ch)
-    bn, bsel = pk_operand2(b, i, ch)
-    assert not bsel
-    if op == 'fma2':
-        return "v_pk_fma_f32 %s, %%[two], %s, %s neg_lo:[0,0,1] neg_hi:[0,0,1]" % (dn, an, bn)
-    mods = ''
-    if asel == 'lo':
-        mods += ' op_sel_hi:[0,1]'
-    elif asel == 'hi':
-        mods += ' op_sel:[1,0]'
-    if op == 'sub':
-        mods += ' neg_lo:[0,1] neg_hi:[0,1]'
-    return "v_pk_%s_f32 %s, %s, %s%s" % ('mul' if op == 'mul' else 'add', dn, an, bn, mods)
+def pk_line2(o, i, ch):
+    return pk_line(o, i, lambda n: pk_operand2(n, i, ch))
 
 
 def block_pk2(kind):
     inst = []
     for i in range(T):
         for ch in 'ab':
-            for (op, d, a, b) in ops(kind):
+            for o in ops(kind):
                 def phys(n):
                     if n == 'x':
                         return 'x%s%d' % (ch, i)
@@ -227,7 +291,7 @@ def block_pk2(kind):
                     if n in ('s1', 's2'):
                         return n + ch
                     return ch + n
-                inst.append(dict(text=pk_line2(op, d, a, b, i, ch), w=phys(d), r=[phys(a), phys(b)]))
+                inst.append(dict(text=pk_line2(o, i, ch), w=phys(o[1]), r=reads(o, phys)))
     lines, slots = schedule(inst, LAT_SLOTS2)
     if os.environ.get('BL_VERBOSE'):
         print("dual %s: %d instructions in %d slots" % (kind, len(inst), slots))
@@ -245,7 +309,7 @@ def block_pk1of2(kind, ch):
         return 't%s%d_%s' % (c, k, j)
     inst = []
     for i in range(T):
-        for (op, d, a, b) in ops(kind):
+        for o in ops(kind):
             def phys(n):
                 if n == 'x':
                     return 'x%s%d' % (ch, i)
@@ -259,21 +323,7 @@ def block_pk1of2(kind, ch):
                 if n[0] == 't':
                     return '%%[%s]' % tname(i, n[1]), ''
                 return pk_operand2(n, i, ch)
-            dn, _ = opnd(d)
-            an, asel = opnd(a)
-            bn, _ = opnd(b)
-            if op == 'fma2':
-                text = "v_pk_fma_f32 %s, %%[two], %s, %s neg_lo:[0,0,1] neg_hi:[0,0,1]" % (dn, an, bn)
-            else:
-                mods = ''
-                if asel == 'lo':
-                    mods += ' op_sel_hi:[0,1]'
-                elif asel == 'hi':
-                    mods += ' op_sel:[1,0]'
-                if op == 'sub':
-                    mods += ' neg_lo:[0,1] neg_hi:[0,1]'
-                text = "v_pk_%s_f32 %s, %s, %s%s" % ('mul' if op == 'mul' else 'add', dn, an, bn, mods)
-            inst.append(dict(text=text, w=phys(d), r=[phys(a), phys(b)]))
+            inst.append(dict(text=pk_line(o, i, opnd), w=phys(o[1]), r=reads(o, phys)))
     return schedule(inst, LAT_SLOTS)[0]
 
 
@@ -294,7 +344,7 @@ def emit_dual(name, kinds, out, with_n=False):
                 ls = []
                 for i in range(T):
                     ls += ["s_cmp_le_u32 %%[n], %d" % i, "s_cbranch_scc1 %s" % nxt]
-                    ls += [pk_line2(op, d, a, b, i, ch) for (op, d, a, b) in ops(kind)]
+                    ls += [pk_line2(o, i, ch) for o in ops(kind)]
                 return ls
             return blk
         lines += [".Ltail_%=:"] + dispatch(kinds, tail_ch('a', '.Ltailb_%='), 'ka', 'ta', '.Ltailb_%=')
@@ -372,7 +422,7 @@ def tail_block(kind, line_fn):
     lines = []
     for i in range(T):
         lines += ["s_cmp_le_u32 %%[n], %d" % i, "s_cbranch_scc1 .Lend_%="]
-        lines += [line_fn(op, d, a, b, i) for (op, d, a, b) in ops(kind)]
+        lines += [line_fn(o, i) for o in ops(kind)]
     return lines
 
 
@@ -408,27 +458,35 @@ HEADER = ["// %s — GENERATED by tools/gen_bandloops.py; do not edit by hand.",
 
 
 def main():
+    global FMA
     allk = [('BQ', 1), ('LP', 2), ('HP', 3), ('PK', 4), ('SH', 5)]
     here = os.environ.get('BL_OUT') or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dspi_amd", "csrc")
-    for fname, packed, note in (("dspi_bandloops.inc", False, "// one stream per lane (v_mul_f32 / v_add_f32 / v_sub_f32), program order"),
-                                ("dspi_bandloops_pk.inc", True, "// two streams per lane (v_pk_mul_f32 / v_pk_add_f32), list-scheduled; needs v2f")):
-        out = [HEADER[0] % fname] + HEADER[1:] + [note, ""]
-        pre = "band16pk" if packed else "band16"
-        emit(pre + "_any", allk, out, packed)
-        if not packed:
-            emit(pre + "_shelf", [('SH', 5)], out, packed)      # loudness stages are shelves (or bypassed)
-        if not packed:      # per-lane parameter kernel: coefficients are per-lane values (VGPRs), the kind is wave-uniform here
-            emit("band16v_any", allk, out, False, vcoef=True)
-            emit("band16v_shelf", [('SH', 5)], out, False, vcoef=True)
-        if packed:
-            emit_n("band16pk_any_n", allk, out)              # kernels for ragged packets: full or short chunk
-            emit_dual("band16pk2_any", allk, out)            # master EQ, left + right interleaved (same kind in both)
-            emit_dual("band16pk2_shelf", [('SH', 5)], out)   # loudness, left + right
-            emit_dual("band16pk2_any_n", allk, out, with_n=True)
-            emit_dual("band16pk2_shelf_n", [('SH', 5)], out, with_n=True)
-        path = os.path.join(here, fname)
-        open(path, "w").write('\n'.join(out))
-        print("wrote", os.path.normpath(path))
+    for fma in (False, True):
+        FMA = fma
+        f = "f" if fma else ""          # the FMA-contract families carry an f: band16pkf_any, band16pk2f_any, band16f_any, band16vf_any ...
+        tag = "_fma" if fma else ""
+        for fname, packed, note in (("dspi_bandloops%s.inc" % tag, False, "// one stream per lane (v_mul_f32 / v_add_f32 / v_sub_f32%s), program order" % (" / v_fma_f32" if fma else "")),
+                                    ("dspi_bandloops_pk%s.inc" % tag, True, "// two streams per lane (v_pk_mul_f32 / v_pk_add_f32%s), list-scheduled; needs v2f" % (" / v_pk_fma_f32" if fma else ""))):
+            out = [HEADER[0] % fname] + HEADER[1:] + [note]
+            if fma:
+                out += ["// FLOAT CONTRACT OF THE FIRMWARE BUILD (DSPI_FLOAT_CONTRACT_FMA): the fused multiply-adds GCC forms for these loops, see ops() in the generator."]
+            out += [""]
+            pre = ("band16pk" if packed else "band16") + f
+            emit(pre + "_any", allk, out, packed)
+            if not packed:
+                emit(pre + "_shelf", [('SH', 5)], out, packed)      # loudness stages are shelves (or bypassed)
+            if not packed:      # per-lane parameter kernel: coefficients are per-lane values (VGPRs), the kind is wave-uniform here
+                emit("band16v%s_any" % f, allk, out, False, vcoef=True)
+                emit("band16v%s_shelf" % f, [('SH', 5)], out, False, vcoef=True)
+            if packed:
+                emit_n(pre + "_any_n", allk, out)                         # kernels for ragged packets: full or short chunk
+                emit_dual("band16pk2%s_any" % f, allk, out)              # master EQ, left + right interleaved (same kind in both)
+                emit_dual("band16pk2%s_shelf" % f, [('SH', 5)], out)     # loudness, left + right
+                emit_dual("band16pk2%s_any_n" % f, allk, out, with_n=True)
+                emit_dual("band16pk2%s_shelf_n" % f, [('SH', 5)], out, with_n=True)
+            path = os.path.join(here, fname)
+            open(path, "w").write('\n'.join(out))
+            print("wrote", os.path.normpath(path))
 
 
 if __name__ == "__main__":
