@@ -102,7 +102,7 @@ float db_to_linear_preset(float db) {   // flash_storage.c:302-306 (powf)
 
 // The firmware's float contract (DSPI_FLOAT_CONTRACT_FMA): GNU C's default -ffp-contract=fast on the Cortex-M33 turns
 // a*b + c into one fused operation; which pairs is a property of GCC's GIMPLE pass (read off -fdump-tree-optimized of the
-// reference sources, oracle/Makefile FMA_FLAGS; oracle/orc_leaf.c carries the same list).  Every mad() in this file is one
+// reference sources; DESIGN.md section 5 lists them with their source lines).  Every mad() in this file is one
 // of those statements: with the contract off it is the reference's expression with separate roundings, with it on the
 // fused form.  (-a)*b + c is c - a*b exactly, so FNMA/FMS need no form of their own.
 inline float mad(bool fma, float a, float b, float c) { return fma ? fmaf(a, b, c) : a * b + c; }
