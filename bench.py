@@ -1,24 +1,39 @@
 #!/usr/bin/env python3
 """bench.py — DSPi chain throughput on MI355X (driver contract: one JSON line on rank 0).
 
-Workload (BASELINE.json configs[2], "config 3"): 65 536 independent stereo streams per GPU, 96 kHz,
-96-frame packets, the full RP2350 11-channel chain (preamp, loudness, 10-band master PEQ, leveller
-with lookahead, BS2B crossfeed, 2x9 matrix, 9 x 10-band output PEQ, gains, 9 delay lines, int24 /
-Q28 conversion).  One "step" = one dspi_process() call = `blocks_per_step` packets for every stream,
-inputs and outputs resident in HBM (DSPI_MEM_DEVICE).  Multi-GPU: one process per GPU, streams
-sharded per rank, no data-path collective (weak scaling: 65 536 streams per GPU); RCCL only for the
-barrier and the max-over-ranks time.
+Default workload (BASELINE.json configs[2], "config 3"): 65 536 independent stereo streams per GPU, 96 kHz, 96-frame
+packets, the full RP2350 11-channel chain (preamp, loudness, 10-band master PEQ, leveller with lookahead, BS2B crossfeed,
+2x9 matrix, 9 x 10-band output PEQ, gains, 9 delay lines, int24 / Q28 conversion).  One "step" = one dspi_process() call
+= `blocks_per_step` packets for every stream, inputs and outputs resident in HBM (DSPI_MEM_DEVICE).
 
-metric  : audio samples/s = frames/s x 11 channels (BASELINE.json "metric")
-roofline: algorithmic HBM bytes (40 B compulsory I/O + 8 B per delayed output =
-          104 B/frame for this configuration) / measured kernel time, against 8 TB/s.
+    python bench.py                         1 GPU, config 3
+    python bench.py --gpus N                N ranks on one node: spawned here (torchrun) when not already under a launcher
+    python bench.py --scaling strong        65 536 streams in total, split over the ranks (dspi_amd/shard.py)
+    python bench.py --config {2,2b,5,perstream,pdm,spdif}     the other BASELINE configs / SURVEY section 8f consumers, same JSON shape
+
+Multi-GPU: one process per GPU, streams sharded per rank, no data-path collective; RCCL only for the barrier and the
+max-over-ranks time.  DSPI_BENCH_BACKEND=gloo lets the ranks share GPUs (control-flow smoke test on a 1-GPU box).
+
+What a line says (config 3):
+  value       frames/s x 11 channels, whole job, on the PRIMARY variant: float contract `--contract` (default fma = the firmware
+              as built: GCC's contracted multiply-adds, include/dspi.h DSPI_FLOAT_CONTRACT_FMA), word layout `--out-layout`,
+              input = SURVEY section 8d's synthetic mix (70 % noise / 10 % sweep / 10 % bursts / 5 % silence / 5 % square)
+  also        the same step measured on the other variants (other contract, other layout, white-noise input), N=1 only
+  roofline    algorithmic HBM bytes / measured kernel time against 8 TB/s.  `frac` uses 104 B/frame (40 B compulsory I/O +
+              8 B per delayed output and frame: the lines live in HBM); `frac_launch_span` uses SURVEY section 8d's lower
+              figure for a launch that spans more frames than a delay (8 * dly / T per frame).  The chain is on the VALU side
+              of the ridge: `valu_fraction` (from the committed PMC profile of the same kernel) is the binding one.
+  cpu_baseline  the reference C path on this box's host cores (a reported baseline, not the target)
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -29,10 +44,12 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_PER_FRAME = 104          # config 3: 4 in + 36 out + 8 * 8 delayed outputs
-CHANNELS = 11
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4.0      # 1024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# HIP events on the context's own stream (torch.cuda.Event only sees torch's stream)
+# ---------------------------------------------------------------------------------------------------------------------
 def hip_runtime():
     for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
         try:
@@ -43,8 +60,6 @@ def hip_runtime():
 
 
 class HipEvents:
-    """HIP events recorded on the context's own stream (torch.cuda.Event only sees torch's stream)."""
-
     def __init__(self, stream_handle: int):
         self.hip = hip_runtime()
         self.stream = ctypes.c_void_p(stream_handle)
@@ -68,57 +83,151 @@ class HipEvents:
         return float(ms.value)
 
 
-def cpu_baseline(fs: int, block_len: int, budget_s: float = 12.0):
-    """The reference C path timed on this box's host cores (rank 0, N=1 only): oracle/_ref (the
-    reference's own leaf sources under our restated orchestrator) when its prebuilt .so is present,
-    else the standalone restatement.  Bounded sample: every host thread runs one independent stream
-    of the same config-3 workload for ~budget_s seconds."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(flavor: int, fs: int, block_len: int, blob, channels: int, fma: bool, vol: int, what: str, budget_s: float = 25.0):
+    """The reference C path timed on this box's host cores.  Preference: the firmware build (the reference's own
+    process_audio_packet + leaf sources compiled in place, oracle/ref_fw.c; one private library copy per thread because the
+    firmware keeps its state in globals), else oracle/_ref (reference leaf sources under the restated orchestrator), else the
+    restatement ("port").  Protocol: CLOCK_MONOTONIC around >= 5 s of work, median of 5 — all host threads,
+    one independent stream each — and 5 x 1 s for the single-core figure; gcc -O3 -march=x86-64-v3, FTZ|DAZ."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
     from dspi_amd import workloads as WL
 
-    use_ref = orclib.ref_available(1)
+    if orclib.ref_available(flavor, "fw", fma): ref, kind, how = "fw", "reference", "the reference's process_audio_packet + leaf sources compiled in place (oracle/_ref/libref_fw_*)"
+    elif orclib.ref_available(flavor, "ref", fma): ref, kind, how = True, "reference", "reference leaf C (oracle/_ref) under the restated orchestrator"
+    else: ref, kind, how = False, "port", "oracle restatement"
     cores = os.cpu_count() or 1
-    blob = WL.full_chain_blob(1)
-    blocks = 250                                    # 0.25 s of audio per call
+    blocks = max(1, int(0.25 * fs / block_len))                     # 0.25 s of audio per call
     pcm = WL.synth_pcm16(1, blocks * block_len, fs, mix=False)[0]
     oracles = []
     for _ in range(cores):
-        o = orclib.Oracle(1, ref=use_ref, detmath=True)
-        o.set_rate(fs); o.set_volume(-20 * 256)
+        o = orclib.Oracle(flavor, ref=ref, detmath=True, fma=fma)
+        o.set_rate(fs); o.set_volume(vol)
         assert o.load_bulk(blob) == 0
         oracles.append(o)
-    # (i) one stream on one core (SURVEY.md §8d): median of 5 runs of ~0.5 s
-    rates = []
-    for _ in range(5):
-        t0 = time.perf_counter(); n1 = 0
-        while time.perf_counter() - t0 < 0.5:
-            oracles[0].process(pcm, blocks, block_len, want_peaks=False); n1 += blocks * block_len
-        rates.append(n1 / (time.perf_counter() - t0))
-    single = sorted(rates)[2]
-    # (ii) one independent stream per hardware thread
-    counts = [0] * cores
-    stop = time.perf_counter() + budget_s
 
-    def work(i):
-        while time.perf_counter() < stop:
-            oracles[i].process(pcm, blocks, block_len, want_peaks=False)   # ctypes releases the GIL
-            counts[i] += blocks * block_len
+    def run_for(seconds, idx):
+        counts = [0] * len(idx)
+        stop = time.perf_counter() + seconds
 
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    dt = time.perf_counter() - t0
-    frames = sum(counts)
+        def work(j, i):
+            while time.perf_counter() < stop:
+                oracles[i].process(pcm, blocks, block_len, want_peaks=False)   # ctypes releases the GIL
+                counts[j] += blocks * block_len
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(j, i)) for j, i in enumerate(idx)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return sum(counts) / (time.perf_counter() - t0)
+
+    single = sorted(run_for(1.0, [0]) for _ in range(5))[2]
+    per = budget_s / 5.0
+    rates = sorted(run_for(per, list(range(cores))) for _ in range(5))
+    fps = rates[2]
     return {
-        "value": frames * CHANNELS / dt, "unit": "samples/s", "cores": cores,
-        "kind": "reference" if use_ref else "port",
-        "sample": f"{cores} threads x 1 stream each, config-3 chain, {frames // cores} frames/thread in {dt:.1f} s "
-                  f"({'reference leaf C (oracle/_ref) under the restated orchestrator' if use_ref else 'oracle restatement'}, gcc -O3, FTZ|DAZ)",
-        "frames_per_s": frames / dt,
+        "value": fps * channels, "unit": "samples/s", "cores": cores, "kind": kind,
+        "sample": f"{what}: {cores} threads x 1 stream each, median of 5 runs of {per:.0f} s ({how}; gcc -O3 -march=x86-64-v3, "
+                  f"{'-ffp-contract=fast (FMA), ' if fma else '-ffp-contract=off, '}FTZ|DAZ)",
+        "frames_per_s": fps, "frames_per_s_min_max": [rates[0], rates[-1]],
         "single_core_frames_per_s": single, "single_core_realtime_x": single / fs,
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic input on the device (SURVEY section 8d)
+# ---------------------------------------------------------------------------------------------------------------------
+def synth_device(torch, dev, S, frames, fs, seed, mix, first_stream=0):
+    """int16 [S][frames][2].  mix: stream classes by (global stream index % 20): 0-13 white noise +-16384 (-6 dBFS), 14-15 log
+    sine sweep 20 Hz -> 20 kHz over the buffer at -12 dBFS with L/R 90 degrees apart, 16-17 speech-like bursts (first half of the
+    buffer at -30 dBFS, second at -6 dBFS: leveller attack / release and gate), 18 digital silence (denormal / FTZ decay after
+    the warm-up), 19 full-scale square (clip flags, s24 saturation).  The buffer is one step and is fed again every step."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    pcm = torch.randint(-16384, 16385, (S, frames, 2), dtype=torch.int16, device=dev, generator=g)
+    if not mix:
+        return pcm
+    cls = (torch.arange(first_stream, first_stream + S, device=dev) % 20)
+    t = torch.arange(frames, device=dev, dtype=torch.float64) / fs
+    dur = frames / fs
+    k = np.log(20000.0 / 20.0) / dur
+    phase = 2 * np.pi * 20.0 * (torch.exp(k * t) - 1.0) / k
+    amp = 32767.0 * 10 ** (-12 / 20.0)
+    sweep = torch.stack([torch.sin(phase), torch.cos(phase)], dim=-1).mul(amp).to(torch.int16)
+    pcm[(cls == 14) | (cls == 15)] = sweep
+    half = frames // 2
+    quiet = (cls == 16) | (cls == 17)
+    pcm[quiet, :half] = (pcm[quiet, :half].to(torch.float32) * (10 ** (-30 / 20.0) / 0.5)).to(torch.int16)
+    pcm[cls == 18] = 0
+    sq = torch.where((torch.arange(frames, device=dev) // 24) % 2 == 0, 32767, -32768).to(torch.int16)
+    pcm[cls == 19] = torch.stack([sq, (-sq.to(torch.int32) - 1).to(torch.int16)], dim=-1)
+    return pcm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+def chain_workload(name):
+    from dspi_amd import workloads as WL
+    if name == "3":
+        return dict(flavor=1, fs=96000, B=96, streams=65536, blocks=50, channels=11, vol=-20 * 256, blob=WL.full_chain_blob(1),
+                    text="BASELINE config 3: full RP2350 chain (preamp+loudness+master PEQ+leveller/lookahead+crossfeed+2x9 matrix+9x10-band PEQ+gain+"
+                         "9 delay lines), 96 kHz, 96-frame packets, int16 in, 4 S/PDIF pairs + PDM sub out")
+    if name in ("2", "2b"):
+        return dict(flavor=1, fs=48000, B=48, streams=4096, blocks=2000, channels=2, vol=-10 * 256, blob=WL.config2_blob(name == "2b"),
+                    text="BASELINE config 2: 4 096 streams, 48 kHz, 48-frame packets, 2 000 packets per launch, master L/R 10-band PEQ only (%s), "
+                         "outputs 0-1 pass-through" % ("all-biquad variant, bands 6.5-20 kHz" if name == "2b" else "SVF below 6.4 kHz + biquad above"))
+    if name == "5":
+        return dict(flavor=0, fs=48000, B=48, streams=16384, blocks=50, channels=7, vol=-20 * 256, blob=WL.full_chain_blob(0),
+                    text="BASELINE config 5: RP2040 Q28 fixed-point 7-channel chain (5 outputs, delays <= 40 ms), 16 384 streams, 48 kHz, 48-frame packets")
+    if name == "perstream":
+        return dict(flavor=1, fs=96000, B=96, streams=16384, blocks=25, channels=11, vol=-20 * 256, blob=WL.full_chain_blob(1), perstream=True,
+                    text="SURVEY 8f-1: config-3 chain, every stream its own preset (one parameter image per stream, per-lane-parameter kernel)")
+    raise SystemExit(f"unknown config {name}")
+
+
+def algorithmic_bytes(w, frames_per_launch):
+    """(per-frame bytes with HBM-resident delay lines, per-frame bytes by SURVEY 8d's launch-span formula)."""
+    from dspi_amd import wire as W
+    flavor, fs, blob = w["flavor"], w["fs"], w["blob"]
+    C, N, _, P, _ = W.dims(flavor)
+    if w["channels"] == 2:                       # config 2: 4 B in + 2 x int32 out (the one live pair)
+        return 12.0, 12.0
+    io = 4 + 4 * (N - 1) + 4                     # int16 stereo in + (N-1) int32 S/PDIF words + the Q28 sub word: 40 B float / 24 B Q28
+    max_d = 4096 if flavor else 2048
+    full = span = float(io)
+    for o in range(N):
+        ms = float(blob["outputs"][o]["delay_ms"]) + (128.0 / fs * 1000.0 if o == N - 1 else 0.0)
+        d = min(max(int(ms * fs / 1000.0), 0), max_d)          # a delay clamped to the line length aliases to 0 samples, but the firmware
+        if d > 0 and blob["outputs"][o]["enabled"]:            # still writes and re-reads the line for it (dly > 0, usb_audio.c:899-911)
+            full += 8.0
+            span += 8.0 * min(1.0, d / float(frames_per_launch))
+    return full, span
+
+
+def latest_profile(kernel_key, contract, layout):
+    """HBM bytes and VALU wave-instructions per frame from the committed PMC profile of this kernel variant (tools/prof.sh +
+    tools/prof_summary.py; counters cannot be collected inside the timed run)."""
+    best = None
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
+        try:
+            t = json.load(open(tpath))
+        except Exception:
+            continue
+        if t.get("kernel_key", "chain3") != kernel_key or t.get("contract", "canonical") != contract or t.get("out_layout", "stream") != layout:
+            continue
+        if t.get("hbm_bytes_per_launch") and t.get("frames_per_launch"):
+            best = dict(source=os.path.basename(tpath), hbm_bytes_per_frame=t["hbm_bytes_per_launch"] / float(t["frames_per_launch"]),
+                        valu_insts_per_frame=(t["valu_insts_per_launch"] / float(t["frames_per_launch"])) if t.get("valu_insts_per_launch") else None)
+    return best
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
 
 
 def main():
@@ -126,71 +235,67 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
-    ap.add_argument("--blocks-per-step", type=int, default=50, help="packets per dspi_process call (50 ms of audio per stream at 96 kHz)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="3", choices=["3", "2", "2b", "5", "perstream", "pdm", "spdif"])
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (weak) or in total (strong); 0 = the config's own")
+    ap.add_argument("--blocks-per-step", type=int, default=0, help="packets per dspi_process call; 0 = the config's own")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--contract", choices=["fma", "canonical"], default="fma", help="float contract of the primary figure (include/dspi.h)")
     ap.add_argument("--out-layout", choices=["tiled", "stream"], default="tiled",
-                    help="sample-word layout in HBM: the kernel's native tiles (DSPI_OUT_TILED) or stream-major S/PDIF pair buffers")
+                    help="sample-word layout in HBM: the kernel's native tiles (DSPI_OUT_TILED) or the firmware's stream-major S/PDIF pair buffers")
+    ap.add_argument("--input", choices=["mix", "noise"], default="mix")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="measure only the primary variant")
     args = ap.parse_args()
 
+    # ---- N ranks without an external launcher: become the launcher ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
-    from dspi_amd import workloads as WL
+    from dspi_amd import wire as W
     from dspi_amd.host import Dspi
+    from dspi_amd.shard import stream_range
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    backend = os.environ.get("DSPI_BENCH_BACKEND", "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernel is the only audio path")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks need {world} GPUs, {torch.cuda.device_count()} visible (DSPI_BENCH_BACKEND=gloo shares devices for a control-flow smoke test)")
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") over xGMI; DSPI_BENCH_BACKEND=gloo exists only to smoke-test the multi-rank control flow on a
-        # box with fewer GPUs than ranks (ranks then share devices)
-        backend = os.environ.get("DSPI_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
+        if backend == "nccl":      # RCCL over xGMI
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    FS, B = 96000, 96
-    S, NB = args.streams, args.blocks_per_step
-    frames = NB * B
-    ctx = Dspi(1, S, device=local_rank)
-    ctx.set_rate(FS)
-    ctx.set_volume(-20 * 256)
-    assert ctx.load_bulk(WL.full_chain_blob(1)) == 0
+    if args.config in ("pdm", "spdif"):
+        out = bench_consumer(args, torch, dev, rank, world, dist, backend)
+    else:
+        out = bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_range)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist: dist.destroy_process_group()
 
-    # synthetic PCM, -6 dBFS white noise, generated on the device (data: "synthetic")
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    pcm = torch.randint(-16384, 16385, (S, frames, 2), dtype=torch.int16, device=dev, generator=g)
-    tiled = args.out_layout == "tiled"
-    R = ctx.tile_streams()
-    tiles = (S + R - 1) // R
-    if tiled:      # [tile][output][frame][R] / [tile][frame][R]  (include/dspi.h, DSPI_OUT_TILED)
-        pairs = torch.empty((tiles, 8, frames, R), dtype=torch.int32, device=dev)
-        sub = torch.empty((tiles, frames, R), dtype=torch.int32, device=dev)
-    else:          # [stream][pair][frame][2] / [stream][frame]
-        pairs = torch.empty((S, 4, frames, 2), dtype=torch.int32, device=dev)
-        sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
-    peaks = torch.empty((S, NB, CHANNELS), dtype=torch.int16, device=dev)
-    torch.cuda.synchronize()
 
-    def step():
-        ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled)
-
+def timed_steps(args, torch, dist, backend, dev, ctx, step):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
     for _ in range(args.warmup):
         step()
     ctx.sync()
     ev = HipEvents(ctx.hip_stream())
     e0, e1 = ev.new(), ev.new()
-
     if dist: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -201,59 +306,162 @@ def main():
     ctx.sync()
     torch.cuda.synchronize()
     if dist: dist.barrier()
-    t1 = time.perf_counter()
-    kernel_ms = ev.elapsed_ms(e0, e1) / args.steps     # one chain-kernel launch per step
-    elapsed = t1 - t0
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev.elapsed_ms(e0, e1) / args.steps
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the only collective: 8 bytes over RCCL/xGMI
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the only collective: 8 bytes
         elapsed = float(t.item())
+    return elapsed, kernel_ms
 
-    total_frames = float(world) * S * frames * args.steps
-    frames_per_s = total_frames / elapsed
-    if rank == 0:
-        achieved_gbs = S * frames * BYTES_PER_FRAME / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/prof.sh + tools/prof_summary.py);
-        # counters cannot be collected inside the timed run, so this is the committed figure of the latest profile
-        traffic, traffic_src, valu_insts = None, None, None
-        import glob
-        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json"))):
-            try:
-                t = json.load(open(tpath))
-                if t.get("out_layout", "stream") == args.out_layout and t.get("hbm_bytes_per_launch"):
-                    scale = S * frames / float(t.get("frames_per_launch", 157286400))      # profile and run may differ in packets per launch
-                    traffic, traffic_src = t["hbm_bytes_per_launch"] * scale, os.path.basename(tpath)
-                    valu_insts = t["valu_insts_per_launch"] * scale if t.get("valu_insts_per_launch") else None
-            except Exception:
-                pass
-        out = {
-            "metric": "audio samples/s (whole node), 96 kHz 11-ch 10-band PEQ; % HBM roofline",
-            "value": frames_per_s * CHANNELS, "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: full RP2350 chain (preamp+loudness+master PEQ+leveller/lookahead+crossfeed+2x9 matrix+9x10-band PEQ+gain+9 delay lines), "
-                                   "96 kHz, 96-frame packets, int16 in, 4 S/PDIF pairs + PDM sub out",
-                       "out_layout": "tiled [tile][output][frame][128] (DSPI_OUT_TILED)" if tiled else "stream-major [stream][pair][frame][2]",
-                       "streams_per_gpu": S, "blocks_per_step": NB, "frames_per_step_per_stream": frames,
-                       "frames_per_s": frames_per_s, "realtime_streams": frames_per_s / FS, "parallelism": f"streams sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "chain_kernel_pk<false, true, false, %s>" % ("true" if tiled else "false"), "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_frame": BYTES_PER_FRAME, "frames_per_launch": S * frames,
-                         # SURVEY.md §8d asks for both sides of the ridge.  VALU: wave-instructions per launch (SQ_INSTS_VALU of the
-                         # committed profile, same workload) / kernel time / (1024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction)
-                         "valu_fraction": (valu_insts / (kernel_ms * 1e-3) / (1024 * 2.4e9 / 4.0)) if valu_insts else None,
-                         "hbm_fraction_measured_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "binds": "valu"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(FS, B)
-            except Exception as e:  # the GPU number stands on its own
-                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out))
+
+def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_range):
+    w = chain_workload(args.config)
+    flavor, FS, B, CH = w["flavor"], w["fs"], w["B"], w["channels"]
+    NB = args.blocks_per_step or w["blocks"]
+    total = args.streams or w["streams"]
+    if args.scaling == "strong":
+        first, last = stream_range(rank, world, total)           # contiguous ranges, SURVEY section 8e
+    else:
+        first, last = rank * total, (rank + 1) * total
+    S = last - first
+    frames = NB * B
+    _, N, _, P, _ = W.dims(flavor)
+    pcm_cache = {}
+
+    def measure(contract, layout, inp):
+        fma = (contract == "fma") and flavor == 1
+        ctx = Dspi(flavor, S, device=dev.index, fma=fma)
+        ctx.set_rate(FS); ctx.set_volume(w["vol"])
+        assert ctx.load_bulk(w["blob"]) == 0
+        if w.get("perstream"):
+            import struct
+            for s in range(S):
+                ctx.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s), stream=s)
+        if inp not in pcm_cache:
+            pcm_cache.clear()
+            pcm_cache[inp] = synth_device(torch, dev, S, frames, FS, 1234 + rank, inp == "mix", first)
+        pcm = pcm_cache[inp]
+        tiled = layout == "tiled"
+        R = ctx.tile_streams(); tiles = (S + R - 1) // R
+        if tiled:      # [tile][output][frame][R] / [tile][frame][R]  (include/dspi.h, DSPI_OUT_TILED)
+            pairs = torch.empty((tiles, 2 * P, frames, R), dtype=torch.int32, device=dev)
+            sub = torch.empty((tiles, frames, R), dtype=torch.int32, device=dev)
+        else:          # [stream][pair][frame][2] / [stream][frame]  (usb_audio.c:934-940)
+            pairs = torch.empty((S, P, frames, 2), dtype=torch.int32, device=dev)
+            sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
+        peaks = torch.empty((S, NB, 2 + N), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        elapsed, kernel_ms = timed_steps(args, torch, dist, backend, dev, ctx,
+                                         lambda: ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled))
+        ctx.close()
+        del pairs, sub, peaks
+        torch.cuda.empty_cache()
+        n_total = total if args.scaling == "strong" else total * world
+        fps = float(n_total) * frames * args.steps / elapsed
+        return dict(contract=contract if flavor == 1 else "integer", out_layout=layout, input=inp, frames_per_s=fps, value=fps * CH,
+                    ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms)
+
+    primary = measure(args.contract, args.out_layout, args.input)
+    also = []
+    if world == 1 and not args.no_variants:
+        other_contract = [("canonical" if args.contract == "fma" else "fma")] if flavor == 1 else []
+        other_layout = "stream" if args.out_layout == "tiled" else "tiled"
+        for c, l, i in [(oc, args.out_layout, args.input) for oc in other_contract] + [(args.contract, other_layout, args.input)] + \
+                       [(oc, other_layout, args.input) for oc in other_contract] + [(args.contract, args.out_layout, "noise" if args.input == "mix" else "mix")]:
+            also.append(measure(c, l, i))
+    if rank != 0:
+        return None
+
+    full_b, span_b = algorithmic_bytes(w, frames)
+    kernel_key = {"3": "chain3", "2": "chain2", "2b": "chain2b", "5": "chain5", "perstream": "perstream"}[args.config]
+
+    def roof(m):
+        per_launch_frames = S * frames
+        ach = per_launch_frames * full_b / (m["kernel_ms"] * 1e-3) / 1e9
+        prof = latest_profile(kernel_key, m["contract"], m["out_layout"])
+        r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "algorithmic_bytes_per_frame": full_b, "algorithmic_bytes_per_frame_launch_span": span_b,
+             "frac_launch_span": per_launch_frames * span_b / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "kernel_ms": m["kernel_ms"], "frames_per_launch": per_launch_frames,
+             "traffic": prof["hbm_bytes_per_frame"] * per_launch_frames if prof else None, "traffic_source": prof["source"] if prof else None,
+             "hbm_fraction_measured_traffic": (prof["hbm_bytes_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof else None,
+             "valu_fraction": (prof["valu_insts_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS) if prof and prof["valu_insts_per_frame"] else None,
+             "binds": "valu"}
+        return r
+
+    if flavor == 1 and not w.get("perstream"):
+        kname = "chain_kernel_pk<false, true, false, %s, %s>" % ("true" if args.out_layout == "tiled" else "false", "true" if args.contract == "fma" else "false")
+        if CH == 2: kname = kname.replace("<false, true", "<false, false")
+    elif flavor == 1:
+        kname = "chain_kernel<1, false, false, %s>" % ("true" if args.contract == "fma" else "false")
+    else:
+        kname = "chain_kernel<0, false, false, false>"
+    roofline = roof(primary)
+    roofline["kernel"] = kname
+    for m in also:
+        r = roof(m)
+        m["roofline_frac"], m["valu_fraction"] = r["frac"], r["valu_fraction"]
+    out = {
+        "metric": "audio samples/s (whole node), 96 kHz 11-ch 10-band PEQ; % HBM roofline",
+        "value": primary["value"], "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": primary["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f32" if flavor else "int32 (Q28)", "data": "synthetic",
+        "config": {"workload": w["text"], "float_contract": ("fma: the firmware as built (GCC -ffp-contract=fast on Cortex-M33), DSPI_FLOAT_CONTRACT_FMA"
+                                                             if args.contract == "fma" else "canonical: no contraction") if flavor else "n/a (integer)",
+                   "out_layout": "tiled [tile][output][frame][row] (DSPI_OUT_TILED)" if args.out_layout == "tiled" else "stream-major [stream][pair][frame][2] (usb_audio.c:934-940)",
+                   "input": "SURVEY 8d synthetic mix (70% noise, 10% sweep, 10% bursts, 5% silence, 5% square)" if args.input == "mix" else "white noise -6 dBFS",
+                   "streams_per_gpu": S, "streams_total": total if args.scaling == "strong" else total * world, "channels": CH,
+                   "blocks_per_step": NB, "frames_per_step_per_stream": frames,
+                   "frames_per_s": primary["frames_per_s"], "realtime_streams": primary["frames_per_s"] / FS, "parallelism": f"streams sharded x{world}"},
+        "roofline": roofline,
+    }
+    if also:
+        out["also"] = also
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(flavor, FS, B, w["blob"], CH, args.contract == "fma" and flavor == 1, w["vol"], f"config {args.config}")
+        except Exception as e:  # the GPU number stands on its own
+            out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    return out
+
+
+def bench_consumer(args, torch, dev, rank, world, dist, backend):
+    """the PDM sigma-delta modulator and the S/PDIF subframe encoder on the bench shape."""
+    from dspi_amd.host import Dspi
+    S = args.streams or 65536
+    F = 2400
+    ctx = Dspi(1, S, device=dev.index)
+    ctx.set_rate(96000)
+    R = ctx.tile_streams(); nt = (S + R - 1) // R
+    tiled = args.out_layout == "tiled"
+    if args.config == "pdm":
+        sub = torch.randint(-(1 << 27), 1 << 27, (nt, F, R) if tiled else (S, F), dtype=torch.int32, device=dev)
+        words = torch.empty((nt * R if tiled else S) * F * 8, dtype=torch.int32, device=dev)
+        step = lambda: ctx.pdm_device(sub.data_ptr(), F, words.data_ptr(), tiled=tiled)
+        per_unit_bytes, unit_name, units = 36.0, "sub samples", S * F
+        text = "SURVEY 8f-2: PDM sigma-delta modulator (256x oversampled, 2nd order, noise-shaped dither), 65 536 streams x 2 400 Q28 samples per call"
+        kernel, bound = "pdm_kernel", "valu (integer)"
+    else:
+        n_in = (nt * R if tiled else S) * 4 * F * 2
+        pairs = torch.randint(-(1 << 23), 1 << 23, (n_in,), dtype=torch.int32, device=dev)
+        outb = torch.empty(n_in * 2, dtype=torch.int32, device=dev)
+        step = lambda: ctx.spdif_device(pairs.data_ptr(), F, 0, outb.data_ptr(), tiled=tiled)
+        per_unit_bytes, unit_name, units = 96.0, "stream-frames (4 pairs)", S * F
+        text = "SURVEY 8f-3: IEC-60958 subframe encoder, 65 536 streams x 4 pairs x 2 400 frames per call"
+        kernel, bound = "spdif_kernel", "hbm"
+    elapsed, kernel_ms = timed_steps(args, torch, dist, backend, dev, ctx, step)
     ctx.close()
-    if dist: dist.destroy_process_group()
+    if rank != 0:
+        return None
+    ups = float(world) * units * args.steps / elapsed
+    ach = units * per_unit_bytes / (kernel_ms * 1e-3) / 1e9
+    return {"metric": f"{unit_name}/s", "value": ups, "unit": f"{unit_name}/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": text, "out_layout": args.out_layout, "streams_per_gpu": S},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_unit": per_unit_bytes, "binds": bound}}
 
 
 if __name__ == "__main__":

@@ -1,16 +1,19 @@
 #!/bin/bash
-# tools/prof.sh <tag> — rocprofv3 kernel trace + PMC passes of the default bench workload (run via gpurun).
+# tools/prof.sh <tag> — rocprofv3 kernel trace + PMC passes of a bench.py workload (run via gpurun).
+# BENCH_ARGS selects the variant, e.g. BENCH_ARGS="--contract canonical --out-layout stream" or "--config 5"; every
+# pass measures the primary variant only (--no-variants).
 set -u
 TAG=${1:-r01}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH_ARGS="${BENCH_ARGS:-} --no-cpu-baseline --no-variants"
+BENCH="python bench.py --steps 3 --warmup 1 $BENCH_ARGS"
 timeout 240 rocprofv3 -L > $OUT/counters.txt 2>&1
 # the trace pass runs more steps so that the per-kernel average is the steady state bench.py times (the first launch of a
 # process touches 10 GB of delay lines for the first time and is ~40 % slower)
-timeout 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py --steps 20 --warmup 3 $BENCH_ARGS > $OUT/trace.log 2>&1
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/pmc_sq1 -o pmc -- $BENCH > $OUT/pmc_sq1.log 2>&1
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE -d $OUT/pmc_sq2 -o pmc -- $BENCH > $OUT/pmc_sq2.log 2>&1
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1

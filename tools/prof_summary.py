@@ -7,9 +7,12 @@ import glob, json, os, sqlite3, sys
 
 src, dst = sys.argv[1], sys.argv[2]
 PACKETS = int(os.environ.get("PACKETS_PER_LAUNCH", 50))      # bench.py --blocks-per-step default
+STREAMS = int(os.environ.get("STREAMS", 65536)); BLOCK = int(os.environ.get("BLOCK_LEN", 96))
+KERNEL_LIKE = os.environ.get("KERNEL_LIKE", "%chain_kernel%")   # which kernel of the run the counters are summed for
+ALGO_BYTES = float(os.environ.get("ALGO_BYTES", 104))
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 lines = [f"# rocprofv3 summary: {os.path.basename(src)}", "", note, "",
-         f"Commands profiled: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (kernel trace) and `--steps 3 --warmup 1` (each PMC pass); config 3: 65 536 streams x {PACKETS} packets x 96 frames per launch = {65536 * PACKETS * 96:,} frames/launch)".replace(",", " "), ""]
+         f"Commands profiled: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline` (kernel trace) and `--steps 3 --warmup 1` (each PMC pass); {os.environ.get('BENCH_ARGS', 'config 3')}: {STREAMS} streams x {PACKETS} packets x {BLOCK} frames per launch = {STREAMS * PACKETS * BLOCK:,} frames/launch)".replace(",", " "), ""]
 tr = os.path.join(src, "trace", "trace_results.db")
 kernel_avg_us = None
 if os.path.exists(tr):
@@ -18,9 +21,9 @@ if os.path.exists(tr):
     for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         short = name if len(name) < 100 else name[:60] + "..." + name[-30:]
         lines.append(f"| `{short}` | {calls} | {total:.1f} | {avg:.1f} | {pct:.2f} |")
-        if "chain_kernel" in name:
+        if KERNEL_LIKE.strip("%") in name:
             kernel_avg_us = avg
-    q = "select name, vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x from kernels where name like '%chain_kernel%' limit 1"
+    q = "select name, vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x from kernels where name like '" + KERNEL_LIKE + "' limit 1"
     try:
         for r in db.execute(q):
             lines += ["", f"chain kernel resources: VGPR {r[1]}, SGPR {r[2]}, LDS {r[3]} B/workgroup, scratch {r[4]} B/lane, workgroup {r[5]}, grid {r[6]}"]
@@ -30,7 +33,7 @@ counters = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_results.db"))):
     db = sqlite3.connect(d)
     try:
-        rows = db.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like '%chain_kernel%' group by counter_name").fetchall()
+        rows = db.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like '" + KERNEL_LIKE + "' group by counter_name").fetchall()
     except Exception as e:
         rows = []
     for n, v, c in rows:
@@ -40,7 +43,7 @@ if counters:
     for n in sorted(counters):
         v, c, p = counters[n]
         lines.append(f"| {n} | {v:.6g} | {p} |")
-    frames = 65536.0 * PACKETS * 96
+    frames = float(STREAMS) * PACKETS * BLOCK
     d = {k: v[0] for k, v in counters.items()}
     lines += ["", "## Derived", ""]
     if "SQ_INSTS_VALU" in d:
@@ -61,12 +64,15 @@ if counters:
         lines.append(f"- WRITE_SIZE = {d['WRITE_SIZE'] * 1024 / 1e9:.3f} GB/launch")
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         tot = d["FETCH_SIZE"] * 2048 + d["WRITE_SIZE"] * 1024
-        lines.append(f"- HBM traffic (2 x FETCH + WRITE) = {tot / 1e9:.3f} GB/launch = {tot / frames:.1f} B/frame (algorithmic: 104 B/frame = {104 * frames / 1e9:.3f} GB/launch)")
+        lines.append(f"- HBM traffic (2 x FETCH + WRITE) = {tot / 1e9:.3f} GB/launch = {tot / frames:.1f} B/frame (algorithmic: {ALGO_BYTES:g} B/frame = {ALGO_BYTES * frames / 1e9:.3f} GB/launch)")
         if kernel_avg_us:
-            lines.append(f"- at {kernel_avg_us:.0f} us/launch: {tot / kernel_avg_us / 1e6:.3f} TB/s moved, {104 * frames / kernel_avg_us / 1e6:.3f} TB/s algorithmic")
+            lines.append(f"- at {kernel_avg_us:.0f} us/launch: {tot / kernel_avg_us / 1e6:.3f} TB/s moved, {ALGO_BYTES * frames / kernel_avg_us / 1e6:.3f} TB/s algorithmic")
         hb["hbm_bytes_per_launch"] = tot
         hb["frames_per_launch"] = frames
         hb["out_layout"] = os.environ.get("OUT_LAYOUT", "tiled")
+        hb["contract"] = os.environ.get("CONTRACT", "fma")            # bench.py's keys for picking the profile of a variant
+        hb["kernel_key"] = os.environ.get("KERNEL_KEY", "chain3")
+        if kernel_avg_us: hb["kernel_avg_us"] = kernel_avg_us
         if "SQ_INSTS_VALU" in d: hb["valu_insts_per_launch"] = d["SQ_INSTS_VALU"]
         json.dump(hb, open(os.path.join(os.path.dirname(dst), "traffic_" + os.path.basename(dst).split("_")[0] + ".json"), "w"))
 os.makedirs(os.path.dirname(dst), exist_ok=True)
