@@ -463,6 +463,26 @@ int dspi_debug_image(dspi_ctx *c, int32_t stream, void *buf, size_t cap) {
     return (int)sizeof(img);
 }
 
+int dspi_debug_eq_taps(dspi_ctx *c, int32_t stream, int channel, const float *x, uint32_t n, float *taps, float *other) {
+    if (!c || !x || !taps || !other || n == 0 || n > (1u << 20) || !valid_stream(c, stream) || stream < 0) return DSPI_E_INVAL;
+    if (c->flavor != DSPI_FLAVOR_RP2350_F32 || channel < 0 || channel >= c->sm.n_ch) return DSPI_E_INVAL;
+    if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
+    HIPCK(c, hipSetDevice(c->device));
+    DevImage img;
+    readable(c, stream).build_image(img);
+    DevImage *d_img = nullptr; float *d_x = nullptr, *d_t = nullptr, *d_o = nullptr;
+    const size_t nb = (size_t)n * sizeof(float);
+    auto done = [&](int rc) { hipFree(d_img); hipFree(d_x); hipFree(d_t); hipFree(d_o); return rc; };
+    if (hipMalloc((void **)&d_img, sizeof img) != hipSuccess || hipMalloc((void **)&d_x, nb) != hipSuccess ||
+        hipMalloc((void **)&d_t, nb * (kBands + 1)) != hipSuccess || hipMalloc((void **)&d_o, nb * kBands) != hipSuccess)
+        return done(fail(c, DSPI_E_NOMEM, "hipMalloc failed (EQ taps)"));
+    if (hipMemcpy(d_img, &img, sizeof img, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_x, x, nb, hipMemcpyHostToDevice) != hipSuccess ||
+        launch_eq_taps(c->fma, d_img, channel, d_x, n, d_t, d_o, c->hs) != hipSuccess || hipStreamSynchronize(c->hs) != hipSuccess ||
+        hipMemcpy(taps, d_t, nb * (kBands + 1), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(other, d_o, nb * kBands, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(c, DSPI_E_HIP, "EQ taps failed"));
+    return done(DSPI_OK);
+}
+
 // ---- PDM sub output: pdm_generator.c:351-397 per sample (dspi_pdm.hip) ----
 static int pdm_state(dspi_ctx *c) {
     if (c->d_pdm) return 0;

@@ -34,6 +34,9 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
                             uint32_t *ring, uint32_t n_streams, hipStream_t stream);
 hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream);
+// debug: taps [kBands+1][n] after every band of EQ channel `ch` of *img (float flavour), other [kBands][n] = the other
+// contract's one-step result from the same input and state
+hipError_t launch_eq_taps(bool fma, const DevImage *img, int ch, const float *x, uint32_t n, float *taps, float *other, hipStream_t stream);
 
 // ---- PDM sub output (dspi_pdm.hip): per-stream state [n_wg][kPdmStateWords][row]: err err2 x1 x2 y1 y2 err_acc rng fade_in_pos
 constexpr int kPdmStateWords = 9;

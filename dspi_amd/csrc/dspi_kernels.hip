@@ -1508,6 +1508,43 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
     return args.fma ? launch_chain_pk<true>(args, leveller_on, n_items, stream) : launch_chain_pk<false>(args, leveller_on, n_items, stream);
 }
 
+// ---- debug: per-band taps of one float EQ channel (include/dspi.h dspi_debug_eq_taps) ----
+// One thread, block-major like the reference loop (dsp_pipeline.c:281-365): band b over the whole buffer from zero state with
+// the production sample loop (band_loop_f32) in the context's contract; `other` gets, for every sample, what the OTHER
+// contract computes from the same input and the same state (a one-step comparison: the per-stage rounding difference).
+template <bool FMA>
+__global__ void eq_taps_kernel(const DevImage *img, int ch, const float *x, uint32_t n, float *taps, float *other) {
+    for (uint32_t i = 0; i < n; ++i) taps[i] = x[i];
+    for (int b = 0; b < kBands; ++b) {
+        const DevBand &bd = img->eq[ch][b];
+        const float c0 = bd.c[0].f, c1 = bd.c[1].f, c2 = bd.c[2].f, c3 = bd.c[3].f, c4 = bd.c[4].f, c5 = bd.c[5].f;
+        float s1 = 0.0f, s2 = 0.0f;
+        const float *in = taps + (size_t)b * n;
+        float *out = taps + (size_t)(b + 1) * n, *alt = other + (size_t)b * n;
+        for (uint32_t i = 0; i < n; ++i) {
+            float xa[T], xb[T];
+            xa[0] = xb[0] = in[i];
+            float a1 = s1, a2 = s2;
+            switch (bd.kind) {
+                case K_BYPASS: break;
+                case K_BIQUAD: band_loop_f32<true, K_BIQUAD, !FMA>(xb, 1, a1, a2, c0, c1, c2, c3, c4, c5); band_loop_f32<true, K_BIQUAD, FMA>(xa, 1, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_LP: band_loop_f32<true, K_SVF_LP, !FMA>(xb, 1, a1, a2, c0, c1, c2, c3, c4, c5); band_loop_f32<true, K_SVF_LP, FMA>(xa, 1, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_HP: band_loop_f32<true, K_SVF_HP, !FMA>(xb, 1, a1, a2, c0, c1, c2, c3, c4, c5); band_loop_f32<true, K_SVF_HP, FMA>(xa, 1, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                case K_SVF_PK: band_loop_f32<true, K_SVF_PK, !FMA>(xb, 1, a1, a2, c0, c1, c2, c3, c4, c5); band_loop_f32<true, K_SVF_PK, FMA>(xa, 1, s1, s2, c0, c1, c2, c3, c4, c5); break;
+                default: band_loop_f32<true, K_SVF_SHELF, !FMA>(xb, 1, a1, a2, c0, c1, c2, c3, c4, c5); band_loop_f32<true, K_SVF_SHELF, FMA>(xa, 1, s1, s2, c0, c1, c2, c3, c4, c5); break;
+            }
+            out[i] = xa[0];
+            alt[i] = xb[0];
+        }
+    }
+}
+
+hipError_t launch_eq_taps(bool fma, const DevImage *img, int ch, const float *x, uint32_t n, float *taps, float *other, hipStream_t stream) {
+    if (fma) hipLaunchKernelGGL(eq_taps_kernel<true>, dim3(1), dim3(1), 0, stream, img, ch, x, n, taps, other);
+    else hipLaunchKernelGGL(eq_taps_kernel<false>, dim3(1), dim3(1), 0, stream, img, ch, x, n, taps, other);
+    return hipGetLastError();
+}
+
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
                             uint32_t *ring, uint32_t n_streams, hipStream_t stream) {
     if (flavor) hipLaunchKernelGGL(state_ops_kernel<1>, dim3(n_items), dim3(1024), 0, stream, items, ops, state, dlines, ring, n_streams);

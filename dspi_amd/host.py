@@ -168,6 +168,14 @@ class Dspi:
         n = self._ck(self.L.dspi_debug_image(self.h, stream, buf, 8192), "debug_image")
         return buf.raw[:n]
 
+    def eq_taps(self, x: np.ndarray, channel: int, stream: int = 0):
+        """dspi_debug_eq_taps: (taps [11][n], other [10][n]) of one EQ channel on the GPU, see include/dspi.h."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        taps = np.zeros((11, x.size), dtype=np.float32); other = np.zeros((10, x.size), dtype=np.float32)
+        self.L.dspi_debug_eq_taps.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        self._ck(self.L.dspi_debug_eq_taps(self.h, stream, channel, x.ctypes.data, x.size, taps.ctypes.data, other.ctypes.data), "debug_eq_taps")
+        return taps, other
+
     # ---- audio ----
     def tile_streams(self) -> int:
         """R of the tiled layouts (dspi.h DSPI_OUT_TILED): 128 float / 64 Q28."""

@@ -42,7 +42,7 @@ extern "C" {
 #endif
 
 #define DSPI_ABI_VERSION 3   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
-                              * dspi_debug_taps (additions only) */
+                              * dspi_debug_eq_taps (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -199,6 +199,15 @@ int dspi_clear_clips(dspi_ctx *ctx, int32_t stream);
 /* ---- introspection for tests (host-side derived parameter image of a stream) ------------ */
 /* Copies the packed device parameter image; returns its size.  Layout is internal (csrc/dspi_image.h). */
 int dspi_debug_image(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
+
+/* Per-band taps of one EQ channel (float flavour; the parity procedure of SURVEY.md section 8d).  x[n] is run through the ten bands
+ * of `channel` (0-1 master, 2.. outputs) of `stream`'s current parameters from zero state, band-major like the firmware's block loop
+ * (dsp_pipeline.c:281-365), with the production sample loop in the context's float contract:
+ *   taps   float [11][n]   taps[0] = x, taps[b+1] = output of band b
+ *   other  float [10][n]   for every sample of band b, what the OTHER contract (canonical <-> DSPI_FLOAT_CONTRACT_FMA) computes from the
+ *                          same input and the same filter state: the per-stage rounding difference between the two
+ * Host buffers; n <= 2^20.  The chain's own state is not touched. */
+int dspi_debug_eq_taps(dspi_ctx *ctx, int32_t stream, int channel, const float *x, uint32_t n, float *taps, float *other);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,9 @@ void orc_get_status(orc_ctx *, void *buf);  /* REQ_GET_STATUS wValue 9 layout: 2
 void orc_process(orc_ctx *, const void *pcm, int bit_depth, uint32_t n_blocks, uint32_t block_len,
                  int32_t *pairs, int32_t *sub, uint16_t *peaks, uint16_t *clip_flags);
 
+/* per-band taps of one EQ channel, float flavour: taps [11][n] (orc_chain.c) */
+int orc_debug_eq_taps(orc_ctx *, int channel, const float *x, uint32_t n, float *taps);
+
 /* debugging taps used by tests */
 const void *orc_tap(orc_ctx *, int what, int *bytes);
 int orc_scalar(orc_ctx *, int what);

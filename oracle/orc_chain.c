@@ -1490,6 +1490,36 @@ void orc_process(orc_ctx *c, const void *pcm, int bit_depth, uint32_t n_blocks, 
     orc_leave(csr);
 }
 
+/* ---- per-band taps of one EQ channel (float flavour; SURVEY.md section 8d parity procedure) ----
+ * x[n] through the ten bands of channel `ch` from zero state, band-major (dsp_pipeline.c:281-365): taps[0] = x,
+ * taps[b+1] = output of band b alone over the whole buffer.  In the _ref builds the band runs in the reference's own
+ * dsp_process_channel_block (all other bands of a scratch copy bypassed); the context is not touched. */
+int orc_debug_eq_taps(orc_ctx *c, int ch, const float *x, uint32_t n, float *taps /*[11][n]*/) {
+#if PICO_RP2350
+    if (ch < 0 || ch >= NUM_CHANNELS) return -1;
+    unsigned csr = orc_enter();
+    Biquad saved[MAX_BANDS];
+    memcpy(saved, c->filters[ch], sizeof saved);
+    memcpy(taps, x, (size_t)n * sizeof(float));
+    for (int b = 0; b < band_counts[ch]; b++) {
+        for (int k = 0; k < MAX_BANDS; k++) {
+            c->filters[ch][k] = saved[k];
+            c->filters[ch][k].s1 = c->filters[ch][k].s2 = 0.0f; c->filters[ch][k].svic1eq = c->filters[ch][k].svic2eq = 0.0f;
+            if (k != b) c->filters[ch][k].bypass = true;
+        }
+        float *out = taps + (size_t)(b + 1) * n;
+        memcpy(out, taps + (size_t)b * n, (size_t)n * sizeof(float));
+        for (uint32_t i = 0; i < n; i += 96) eq_block(c, ch, out + i, (n - i) < 96 ? (n - i) : 96);
+    }
+    memcpy(c->filters[ch], saved, sizeof saved);
+    orc_leave(csr);
+    return 0;
+#else
+    (void)c; (void)ch; (void)x; (void)n; (void)taps;
+    return -1;
+#endif
+}
+
 /* ---- state taps for tests ---- */
 const void *orc_tap(orc_ctx *c, int what, int *bytes) {
     switch (what) {

@@ -206,6 +206,15 @@ class Oracle:
         self.lib.orc_get_status(self.h, buf)
         return buf.raw
 
+    def eq_taps(self, x: np.ndarray, channel: int) -> np.ndarray:
+        """orc_debug_eq_taps: float [11][n], x through the ten bands of `channel` from zero state (float flavour, not the fw build)."""
+        self._sync()
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        taps = np.zeros((11, x.size), dtype=np.float32)
+        self.lib.orc_debug_eq_taps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+        assert self.lib.orc_debug_eq_taps(self.h, channel, x.ctypes.data, x.size, taps.ctypes.data) == 0
+        return taps
+
     def tap(self, what: int) -> bytes:
         n = C.c_int(0)
         p = self.lib.orc_tap(self.h, what, C.byref(n))

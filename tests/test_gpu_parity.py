@@ -406,3 +406,30 @@ def test_spdif_subframes(flavor):
                     assert n2 == nxt and np.array_equal(ref, sf[s_, p_]), (fs, c, s_, p_)
             pos = nxt
         d.close(); dt.close()
+
+
+def test_per_band_taps_both_contracts():
+    """SURVEY.md section 8d parity procedure: taps after every band (dspi_debug_eq_taps, the production sample loop).  Both GPU
+    contracts against the oracle tap for tap — the reference's dsp_process_channel_block compiled without / with contraction where
+    oracle/_ref is present — and the one-step difference between the contracts bounded per stage (tools/ulp_report.py prints the
+    full table, profiles/r02_ulp_per_stage.md)."""
+    fs, n = 96000, 6000
+    rng = np.random.default_rng(3)
+    x = (rng.integers(-16384, 16385, n) / 32768.0 * 0.7079).astype(np.float32)
+    blob = WL.full_chain_blob(1)
+    use_ref = orclib.ref_available(1, "ref") and orclib.ref_available(1, "ref", True)
+    for fma in (False, True):
+        d = Dspi(1, 3, device=0, fma=fma); o = Oracle(1, ref=use_ref, fma=fma)
+        for z in (d, o):
+            assert z.set_rate(fs) == 0
+            z.set_volume(-20 * 256)
+            assert z.load_bulk(blob) == 0
+        for ch in (0, 1, 2, 5, 9, 10):
+            taps, other = d.eq_taps(x, ch, stream=1)
+            assert np.array_equal(taps.view(np.uint32), o.eq_taps(x, ch).view(np.uint32)), f"taps of channel {ch}, fma={fma}"
+            if not fma:      # canonical trajectory, firmware-contract one-step result beside it
+                for b in range(10):
+                    peak = float(np.abs(taps[b + 1]).max())
+                    if peak > 0:
+                        assert float(np.abs(taps[b + 1] - other[b]).max()) <= 2.0 * float(np.spacing(np.float32(peak))), (ch, b)
+        d.close()

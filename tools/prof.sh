@@ -18,5 +18,9 @@ timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_IN
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE -d $OUT/pmc_sq2 -o pmc -- $BENCH > $OUT/pmc_sq2.log 2>&1
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
-find $OUT -name "*.csv" | head -50
+# the rocpd databases carry the whole code object (~50 MB each since the library holds both kernel families) and gpurun
+# only returns 64 MiB: summarise on the box, keep the summary (+ traffic json) and drop the databases
+mkdir -p gpurun_out/profsum
+python tools/prof_summary.py $OUT gpurun_out/profsum/${TAG}_summary.md "${NOTE:-}"
+find $OUT -name "*.db" -size +8M -delete
 du -sh $OUT
