@@ -47,6 +47,7 @@ struct dspi_ctx {
     // device
     hipStream_t hs = nullptr;
     uint32_t *d_state = nullptr, *d_dlines = nullptr, *d_ring = nullptr;
+    uint32_t *d_xwords = nullptr; size_t d_xwords_cap = 0;      // exchange area of the packed kernel's copy wave (stream-major output)
     DevImage *d_images = nullptr;
     std::vector<uint32_t> image_flags;             // DevImage::flags of each uploaded image (kernel variant selection)
     size_t d_images_cap = 0;
@@ -353,7 +354,7 @@ void dspi_destroy(dspi_ctx *c) {
     if (c->device != DSPI_DEVICE_NONE) {
         (void)hipSetDevice(c->device);
         if (c->hs) (void)hipStreamSynchronize(c->hs);
-        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_stream_image, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
+        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_xwords, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_stream_image, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
             if (p) (void)hipFree(p);
         if (c->hs) (void)hipStreamDestroy(c->hs);
@@ -582,6 +583,11 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.n_streams = c->n_streams; a.n_blocks = n_blocks; a.block_len = block_len; a.bit_depth = (uint32_t)bit_depth;
     a.tiled_out = tiled ? 1u : 0u;
     a.fma = c->fma ? 1u : 0u;
+    if (c->flavor && !tiled && (out->pairs || out->sub)) {      // stream-major words of the packed kernel go through its exchange area
+        const size_t xb = (size_t)c->n_wg * 2 * kMaxOut * kChunk * c->sm.row * 4;
+        if ((rc = ensure(c, c->d_xwords, c->d_xwords_cap, xb))) return rc;
+        a.xwords = c->d_xwords;
+    }
     if (dev) {
         a.pcm = pcm_in; a.pairs = out->pairs; a.sub = out->sub; a.peaks = out->peaks;
     } else {
