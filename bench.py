@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--blocks-per-step", type=int, default=0, help="packets per dspi_process call; 0 = the config's own")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--contract", choices=["fma", "canonical"], default="fma", help="float contract of the primary figure (include/dspi.h)")
-    ap.add_argument("--out-layout", choices=["tiled", "stream"], default="tiled",
+    ap.add_argument("--out-layout", choices=["tiled", "stream"], default="stream",
                     help="sample-word layout in HBM: the kernel's native tiles (DSPI_OUT_TILED) or the firmware's stream-major S/PDIF pair buffers")
     ap.add_argument("--input", choices=["mix", "noise"], default="mix")
     ap.add_argument("--no-cpu-baseline", action="store_true")

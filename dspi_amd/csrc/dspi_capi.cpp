@@ -584,7 +584,6 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.n_streams = c->n_streams; a.n_blocks = n_blocks; a.block_len = block_len; a.bit_depth = (uint32_t)bit_depth;
     a.tiled_out = tiled ? 1u : 0u;
     a.fma = c->fma ? 1u : 0u;
-    { const char *e = getenv("DSPI_DBG"); a.dbg = e ? (uint32_t)atoi(e) : 0u; }
     if (c->flavor && !tiled && (out->pairs || out->sub)) {      // stream-major words of the packed kernel go through its exchange area
         const size_t xb = (size_t)c->n_wg * 2 * kMaxOut * kChunk * c->sm.row * 4;
         if ((rc = ensure(c, c->d_xwords, c->d_xwords_cap, xb))) return rc;

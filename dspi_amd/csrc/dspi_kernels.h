@@ -23,7 +23,6 @@ struct KArgs {
     const uint32_t *stream_image;   // [n_streams] image index of every stream (float one-stream kernel: per-lane parameters)
     uint32_t tiled_out;      // DSPI_OUT_TILED: pairs = [tile][output][frames][row], sub = [tile][frames][row] (row = StateMap::row)
     uint32_t *xwords;        // packed float kernel, stream-major output: exchange area [n_wg][2][kMaxOut][kChunk][128] words (or null: scattered stores)
-    uint32_t dbg;            // development experiments (DSPI_DBG environment variable), 0 in production
     uint32_t fma;            // float flavour: the context's contract is DSPI_FLOAT_CONTRACT_FMA (selects the kernel family at launch)
 };
 
