@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/prof_all.sh <round tag> — rocprofv3 trace + PMC summaries of every kernel the bench can drive (run via gpurun); the
+# summaries land in gpurun_out/profsum/ and are copied to profiles/ by hand.
+R=${1:-r02}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+run() { # tag, bench args, env...
+  local tag=$1 args=$2; shift 2
+  env BENCH_ARGS="$args" "$@" bash tools/prof.sh ${R}${tag} > gpurun_out/prof_${R}${tag}.log 2>&1
+  tail -4 gpurun_out/prof_${R}${tag}.log
+}
+run b "--contract fma --out-layout stream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain3 NOTE="config 3, firmware float contract (FMA), stream-major words through the copy wave: the bench default"
+run c "--contract canonical --out-layout tiled" CONTRACT=canonical OUT_LAYOUT=tiled KERNEL_KEY=chain3 NOTE="config 3, canonical contract, tiled words (round-1 configuration)"
+run d "--contract canonical --out-layout stream" CONTRACT=canonical OUT_LAYOUT=stream KERNEL_KEY=chain3 NOTE="config 3, canonical contract, stream-major words"
+run e "--config 5" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=chain5 STREAMS=16384 BLOCK_LEN=48 ALGO_BYTES=56 KERNEL_LIKE="%chain_kernel<0%" NOTE="config 5: Q28 7-channel chain, 16 384 streams, 48 kHz"
+run f "--config perstream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=perstream STREAMS=16384 PACKETS_PER_LAUNCH=25 KERNEL_LIKE="%chain_kernel<1%" NOTE="every stream its own preset: per-lane-parameter float kernel"
+run g "--config pdm --out-layout tiled" CONTRACT=integer OUT_LAYOUT=tiled KERNEL_KEY=pdm PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=36 KERNEL_LIKE="%pdm_kernel%" NOTE="PDM sigma-delta modulator, 65 536 streams x 2 400 samples (frames = sub samples)"
+run h "--config spdif --out-layout stream" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=spdif PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=96 KERNEL_LIKE="%spdif%" NOTE="S/PDIF subframe encoder, 65 536 streams x 4 pairs x 2 400 frames"
+ls gpurun_out/profsum
