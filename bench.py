@@ -9,7 +9,7 @@ packets, the full RP2350 11-channel chain (preamp, loudness, 10-band master PEQ,
     python bench.py                         1 GPU, config 3
     python bench.py --gpus N                N ranks on one node: spawned here (torchrun) when not already under a launcher
     python bench.py --scaling strong        65 536 streams in total, split over the ranks (dspi_amd/shard.py)
-    python bench.py --config {2,2b,5,perstream,pdm,spdif}     the other BASELINE configs / SURVEY section 8f consumers, same JSON shape
+    python bench.py --config {2,2b,5,perstream,pdm,spdif,i2s}     the other BASELINE configs / SURVEY section 8f consumers, same JSON shape
 
 Multi-GPU: one process per GPU, streams sharded per rank, no data-path collective; RCCL only for the barrier and the
 max-over-ranks time.  DSPI_BENCH_BACKEND=gloo lets the ranks share GPUs (control-flow smoke test on a 1-GPU box).
@@ -235,7 +235,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="3", choices=["3", "2", "2b", "5", "perstream", "pdm", "spdif"])
+    ap.add_argument("--config", default="3", choices=["3", "2", "2b", "5", "perstream", "pdm", "spdif", "i2s"])
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (weak) or in total (strong); 0 = the config's own")
     ap.add_argument("--blocks-per-step", type=int, default=0, help="packets per dspi_process call; 0 = the config's own")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -280,7 +280,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    if args.config in ("pdm", "spdif"):
+    if args.config in ("pdm", "spdif", "i2s"):
         out = bench_consumer(args, torch, dev, rank, world, dist, backend)
     else:
         out = bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_range)
@@ -443,6 +443,14 @@ def bench_consumer(args, torch, dev, rank, world, dist, backend):
         per_unit_bytes, unit_name, units = 36.0, "sub samples", S * F
         text = "SURVEY 8f-2: PDM sigma-delta modulator (256x oversampled, 2nd order, noise-shaped dither), 65 536 streams x 2 400 Q28 samples per call"
         kernel, bound = "pdm_kernel", "valu (integer)"
+    elif args.config == "i2s":
+        n_in = (nt * R if tiled else S) * 4 * F * 2
+        pairs = torch.randint(-(1 << 23), 1 << 23, (n_in,), dtype=torch.int32, device=dev)
+        outb = torch.empty(n_in, dtype=torch.int32, device=dev)
+        step = lambda: ctx.i2s_device(pairs.data_ptr(), F, 0xF, outb.data_ptr(), tiled=tiled)
+        per_unit_bytes, unit_name, units = 64.0, "stream-frames (4 pairs)", S * F
+        text = "SURVEY 8f-3: I2S slot words (left-justified 24-bit in 32-bit slots), 65 536 streams x 4 pairs x 2 400 frames per call"
+        kernel, bound = "i2s_kernel", "hbm"
     else:
         n_in = (nt * R if tiled else S) * 4 * F * 2
         pairs = torch.randint(-(1 << 23), 1 << 23, (n_in,), dtype=torch.int32, device=dev)

@@ -84,14 +84,12 @@ bool valid_stream(const dspi_ctx *c, int32_t s) { return s == DSPI_ALL_STREAMS |
 Params *writable(dspi_ctx *c, int32_t stream) {
     int32_t idx = c->stream_image[(size_t)stream];
     if (c->image_refs[(size_t)idx] > 1) {
-        size_t slot = c->images.size();
-        for (size_t i = 0; i < c->images.size(); i++) if (c->image_refs[i] == 0) { slot = i; break; }
+        // a reference count never drops to zero (the last stream of an image keeps it), so clones always append
+        const size_t slot = c->images.size();
         auto clone = std::make_unique<Params>(*c->images[(size_t)idx]);
         clone->dirty = true;
-        if (slot == c->images.size()) { c->images.push_back(std::move(clone)); c->image_refs.push_back(0); }
-        else c->images[slot] = std::move(clone);
+        c->images.push_back(std::move(clone)); c->image_refs.push_back(1);
         c->image_refs[(size_t)idx]--;
-        c->image_refs[slot] = 1;
         c->stream_image[(size_t)stream] = (int32_t)slot;
         c->assignment_dirty = true;
         idx = (int32_t)slot;
@@ -237,7 +235,7 @@ int commit_params(dspi_ctx *c) {
     if (c->assignment_dirty) { int rc = rebuild_assignment(c); if (rc) return rc; }
     const size_t ni = c->images.size();
     bool any_dirty = false;
-    for (size_t i = 0; i < ni; i++) if (c->image_refs[i] && c->images[i]->dirty) any_dirty = true;
+    for (size_t i = 0; i < ni; i++) if (c->images[i]->dirty) any_dirty = true;
     if (any_dirty || ni * sizeof(DevImage) > c->d_images_cap) HIPCK(c, hipStreamSynchronize(c->hs));   // no launch may still be reading an image we overwrite
     if (ni * sizeof(DevImage) > c->d_images_cap) {
         DevImage *old = c->d_images; size_t oldcap = c->d_images_cap;
@@ -247,25 +245,39 @@ int commit_params(dspi_ctx *c) {
         if (old) { HIPCK(c, hipMemcpy(c->d_images, old, oldcap, hipMemcpyDeviceToDevice)); HIPCK(c, hipFree(old)); }
         for (auto &p : c->images) p->dirty = true;
     }
+    // dirty images go up in contiguous runs (per-stream presets dirty thousands at once)
+    if (c->image_flags.size() < ni) c->image_flags.resize(ni, 0u);
+    std::vector<DevImage> run;
+    size_t run0 = 0;
+    auto flush = [&]() -> int {
+        if (!run.empty()) HIPCK(c, hipMemcpy(c->d_images + run0, run.data(), run.size() * sizeof(DevImage), hipMemcpyHostToDevice));
+        run.clear();
+        return 0;
+    };
     for (size_t i = 0; i < ni; i++) {
         Params &p = *c->images[i];
-        if (c->image_refs[i] == 0) continue;
-        if (p.dirty) {
-            DevImage img;
-            p.build_image(img);
-            if (c->image_flags.size() <= i) c->image_flags.resize(i + 1, 0u);
-            if ((c->image_flags[i] ^ img.flags) & IF_LEVELLER_ON) c->launch_dirty = true;
-            c->image_flags[i] = img.flags;
-            HIPCK(c, hipMemcpy(c->d_images + i, &img, sizeof(img), hipMemcpyHostToDevice));   // synchronous: `img` is a local
-            p.dirty = false;
-        }
-        if (ops_pending(p.ops)) {
-            const auto &items = c->image_items[0][i];
-            if (!items.empty())
-                HIPCK(c, launch_state_ops(c->flavor, c->d_items + c->image_item_offset[0][i], (uint32_t)items.size(), p.ops, c->d_state, c->d_dlines,
-                                          c->d_ring, c->n_streams, c->hs));
-            p.ops = StateOps{};
-        }
+        if (!p.dirty) { int rc = flush(); if (rc) return rc; continue; }
+        if (run.empty()) run0 = i;
+        run.emplace_back();
+        p.build_image(run.back());
+        if ((c->image_flags[i] ^ run.back().flags) & IF_LEVELLER_ON) c->launch_dirty = true;
+        c->image_flags[i] = run.back().flags;
+        p.dirty = false;
+    }
+    { int rc = flush(); if (rc) return rc; }
+    // pending state mutations: consecutive images with the same mutation share one launch (their workgroup items are
+    // consecutive in d_items, list 0)
+    for (size_t i = 0; i < ni;) {
+        Params &p = *c->images[i];
+        if (!ops_pending(p.ops)) { i++; continue; }
+        size_t j = i + 1;
+        while (j < ni && memcmp(&c->images[j]->ops, &p.ops, sizeof(StateOps)) == 0) j++;
+        const uint32_t first = c->image_item_offset[0][i];
+        const uint32_t count = (uint32_t)((j < ni ? c->image_item_offset[0][j] : c->image_item_offset[0][ni - 1] + (uint32_t)c->image_items[0][ni - 1].size()) - first);
+        if (count)
+            HIPCK(c, launch_state_ops(c->flavor, c->d_items + first, count, p.ops, c->d_state, c->d_dlines, c->d_ring, c->n_streams, c->hs));
+        for (size_t k = i; k < j; k++) c->images[k]->ops = StateOps{};
+        i = j;
     }
     if (c->launch_dirty) { int rc = rebuild_launch_lists(c); if (rc) return rc; }
     return 0;
@@ -274,6 +286,7 @@ int commit_params(dspi_ctx *c) {
 int read_stream_words(dspi_ctx *c, uint32_t stream, int slot0, int count, uint32_t *out) {
     const uint32_t row = (uint32_t)c->sm.row, wg = stream / row, col = stream % row;
     const uint32_t *src = c->d_state + ((size_t)wg * c->sm.n_slots + slot0) * row + col;
+    HIPCK(c, hipSetDevice(c->device));            // several contexts on different GPUs may share the process
     HIPCK(c, hipStreamSynchronize(c->hs));
     HIPCK(c, hipMemcpy2D(out, 4, src, (size_t)row * 4, 4, (size_t)count, hipMemcpyDeviceToHost));
     return 0;
@@ -294,6 +307,7 @@ int fetch_status(dspi_ctx *c, int32_t stream, uint16_t *peaks, uint16_t *clip) {
 
 int zero_clips(dspi_ctx *c, int32_t stream) {
     if (c->device == DSPI_DEVICE_NONE) return 0;
+    HIPCK(c, hipSetDevice(c->device));
     HIPCK(c, hipStreamSynchronize(c->hs));
     const size_t row = (size_t)c->sm.row, pitch = (size_t)c->sm.n_slots * row * 4;
     if (stream == DSPI_ALL_STREAMS) {
@@ -424,12 +438,14 @@ int dspi_vendor_get(dspi_ctx *c, int32_t stream, uint8_t req, uint16_t wValue, v
         *(uint8_t *)buf = 0;
         return 1;
     }
-    if (req == 0xD6) {   // REQ_SAVE_MASTER_VOLUME mutates the directory copy
+    if (req == 0xD6 || req == 0xC0) {   // REQ_SAVE_MASTER_VOLUME mutates the directory copy, REQ_SET_OUTPUT_TYPE the slot type (+ pipeline mute)
         return for_targets(c, stream, [&](Params &p) { int r = p.vendor_get(req, wValue, buf, cap, peaks, &clip); return r < 0 ? r : 0; }) == 0 ? 1 : DSPI_E_SHORT;
     }
     Params tmp_view = readable(c, stream);    // GETs never change parameters; work on a copy
     n = tmp_view.vendor_get(req, wValue, buf, cap, peaks, &clip);
-    if (req == 0x83 && n >= 0 && before != 0) { int rc = zero_clips(c, stream); if (rc) return rc; }
+    // REQ_CLEAR_CLIPS: with DSPI_ALL_STREAMS the answer carries stream 0's flags (one device answers one request), but every
+    // stream's sticky bits are cleared whatever stream 0 held
+    if (req == 0x83 && n >= 0 && (before != 0 || stream == DSPI_ALL_STREAMS)) { int rc = zero_clips(c, stream); if (rc) return rc; }
     return n;
 }
 int dspi_set_host_volume(dspi_ctx *c, int32_t stream, int16_t v) {
@@ -474,7 +490,7 @@ int dspi_debug_eq_taps(dspi_ctx *c, int32_t stream, int channel, const float *x,
     readable(c, stream).build_image(img);
     DevImage *d_img = nullptr; float *d_x = nullptr, *d_t = nullptr, *d_o = nullptr;
     const size_t nb = (size_t)n * sizeof(float);
-    auto done = [&](int rc) { hipFree(d_img); hipFree(d_x); hipFree(d_t); hipFree(d_o); return rc; };
+    auto done = [&](int rc) { (void)hipFree(d_img); (void)hipFree(d_x); (void)hipFree(d_t); (void)hipFree(d_o); return rc; };
     if (hipMalloc((void **)&d_img, sizeof img) != hipSuccess || hipMalloc((void **)&d_x, nb) != hipSuccess ||
         hipMalloc((void **)&d_t, nb * (kBands + 1)) != hipSuccess || hipMalloc((void **)&d_o, nb * kBands) != hipSuccess)
         return done(fail(c, DSPI_E_NOMEM, "hipMalloc failed (EQ taps)"));
@@ -552,6 +568,36 @@ int dspi_spdif_encode(dspi_ctx *c, const int32_t *pairs, uint32_t n_frames, uint
         HIPCK(c, hipStreamSynchronize(c->hs));
     }
     return (int)((block_pos + n_frames) % 192u);
+}
+
+// ---- I2S slots: pico_audio_i2s_multi/audio_i2s_multi.c:217-226 (dspi_spdif.hip) ----
+int dspi_i2s_encode(dspi_ctx *c, const int32_t *pairs, uint32_t n_frames, uint32_t pair_mask, uint32_t *words, uint32_t flags) {
+    if (!c || !pairs || !words || n_frames == 0 || (pair_mask >> c->sm.n_pairs) != 0) return DSPI_E_INVAL;
+    if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
+    HIPCK(c, hipSetDevice(c->device));
+    if (pair_mask == DSPI_I2S_PAIRS_BY_TYPE) {          // the slots whose output type is I2S (output_types[], REQ_SET_OUTPUT_TYPE)
+        const Params &p = readable(c, DSPI_ALL_STREAMS);
+        for (int i = 0; i < c->sm.n_pairs; i++) if (p.output_types[i] == 1) pair_mask |= 1u << i;
+        if (pair_mask == 0) return 0;
+    }
+    const bool tiled = flags & DSPI_OUT_TILED, dev = flags & DSPI_MEM_DEVICE;
+    const size_t cols = tiled ? (size_t)c->n_wg * c->sm.row : (size_t)c->n_streams;
+    const size_t bytes = cols * c->sm.n_pairs * n_frames * 8;
+    const int32_t *d_in = pairs;
+    uint32_t *d_out = words;
+    int rc;
+    if (!dev) {
+        if ((rc = ensure(c, c->d_spdif_in, c->d_spdif_in_cap, bytes)) || (rc = ensure(c, c->d_spdif_out, c->d_spdif_out_cap, bytes))) return rc;
+        HIPCK(c, hipMemcpyAsync(c->d_spdif_in, pairs, bytes, hipMemcpyHostToDevice, c->hs));
+        HIPCK(c, hipMemcpyAsync(c->d_spdif_out, words, bytes, hipMemcpyHostToDevice, c->hs));     // pairs outside the mask keep the caller's words
+        d_in = c->d_spdif_in; d_out = c->d_spdif_out;
+    }
+    HIPCK(c, launch_i2s(tiled, d_in, d_out, c->n_streams, (uint32_t)c->sm.n_pairs, n_frames, (uint32_t)c->sm.row, c->n_wg, pair_mask, c->hs));
+    if (!dev) {
+        HIPCK(c, hipMemcpyAsync(words, c->d_spdif_out, bytes, hipMemcpyDeviceToHost, c->hs));
+        HIPCK(c, hipStreamSynchronize(c->hs));
+    }
+    return (int)pair_mask;
 }
 
 int dspi_sync(dspi_ctx *c) {

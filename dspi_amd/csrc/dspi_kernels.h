@@ -48,5 +48,8 @@ hipError_t launch_pdm_reset(uint32_t *state, uint32_t n_streams, uint32_t row, u
 // ---- S/PDIF subframe encoder (dspi_spdif.hip)
 hipError_t launch_spdif(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
                         uint32_t n_wg, uint32_t block_pos, uint32_t fs, hipStream_t stream);
+// I2S slots (audio_i2s_multi.c:217-226): words << 8 for the pairs in pair_mask; same layouts as the pair words themselves
+hipError_t launch_i2s(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
+                      uint32_t n_wg, uint32_t pair_mask, hipStream_t stream);
 
 }  // namespace dspi

@@ -44,6 +44,7 @@ enum : uint8_t {
     REQ_SET_LEVELLER_SPEED = 0xB8, REQ_GET_LEVELLER_SPEED = 0xB9, REQ_SET_LEVELLER_MAX_GAIN = 0xBA, REQ_GET_LEVELLER_MAX_GAIN = 0xBB,
     REQ_SET_LEVELLER_LOOKAHEAD = 0xBC, REQ_GET_LEVELLER_LOOKAHEAD = 0xBD, REQ_SET_LEVELLER_GATE = 0xBE, REQ_GET_LEVELLER_GATE = 0xBF,
     REQ_SET_PREAMP_CH = 0xD0, REQ_GET_PREAMP_CH = 0xD1, REQ_SET_MASTER_VOLUME = 0xD2, REQ_GET_MASTER_VOLUME = 0xD3,
+    REQ_SET_OUTPUT_TYPE = 0xC0, REQ_GET_OUTPUT_TYPE = 0xC1,
     REQ_SET_MASTER_VOLUME_MODE = 0xD4, REQ_GET_MASTER_VOLUME_MODE = 0xD5, REQ_SAVE_MASTER_VOLUME = 0xD6, REQ_GET_SAVED_MASTER_VOLUME = 0xD7,
 };
 
@@ -764,6 +765,7 @@ int Params::load_slot(const void *image, size_t len, int expect_slot) {
     if (len < (size_t)slot_size()) return 3;    // PRESET_ERR_CRC
     FtzScope ftz;
     pipeline_mute(kPresetMuteSamples);
+    uint8_t old_types[4]; memcpy(old_types, output_types, 4);
     SlotCursor c(image);
     uint32_t magic = c.get<uint32_t>();
     uint16_t version = c.get<uint16_t>();
@@ -855,6 +857,9 @@ int Params::load_slot(const void *image, size_t len, int expect_slot) {
         uint64_t hold = ((uint64_t)freq * 10u + 999u) / 1000u;
         pipeline_mute(hold < 512u ? 512u : (uint32_t)hold);
     }
+    // a preset that changes an output slot's type goes through process_type_switches, which arms the mute once more
+    // with PRESET_MUTE_SAMPLES (main.c:957-972, :279)
+    if (memcmp(old_types, output_types, (size_t)n_pairs) != 0) pipeline_mute(kPresetMuteSamples);
     service();
     return 0;
 }
@@ -1142,6 +1147,14 @@ int Params::vendor_get(uint8_t req, uint16_t wValue, void *buf, uint16_t cap, co
         case REQ_GET_CHANNEL_NAME: return idx < n_ch ? put(names[idx], 32) : -14;
         case REQ_GET_ALL_PARAMS: return collect_bulk(buf, cap);
         case REQ_FACTORY_RESET: factory_reset(); return put_u8(0);
+        case REQ_SET_OUTPUT_TYPE: {     // usb_audio.c:2984-3016; the deferred switch (main.c:230-424) is taken at once: its DSP side
+            const uint8_t slot = wValue & 0xFF, type = (wValue >> 8) & 0xFF;     // effect is the pipeline mute (main.c:279)
+            if (slot >= n_pairs) return put_u8(0x03);      // PIN_CONFIG_INVALID_OUTPUT
+            if (type > 1) return put_u8(0x01);             // PIN_CONFIG_INVALID_PIN
+            if (type != output_types[slot]) { output_types[slot] = type; pipeline_mute(kPresetMuteSamples); }
+            return put_u8(0x00);
+        }
+        case REQ_GET_OUTPUT_TYPE: return idx < n_pairs ? put_u8(output_types[idx]) : -14;
         default: return -14;
     }
 }

@@ -1,4 +1,5 @@
-// dspi_spdif.hip — IEC 60958 (S/PDIF) subframe encoding of the chain's int24 pair words on the GPU.
+// dspi_spdif.hip — output wire formats of the chain's int24 pair words on the GPU: IEC 60958 (S/PDIF)
+// subframe encoding, and the I2S slots' left-justified words (at the end of the file).
 //
 // Reference: firmware/pico-extras/src/rp2_common/pico_audio_spdif_multi/ — what DSPi's S/PDIF outputs do to the words
 // of dspi_out.pairs before the PIO shifts them out:
@@ -91,7 +92,41 @@ __global__ __launch_bounds__(256) void spdif_kernel_frames(const int32_t *pairs,
     *reinterpret_cast<u4 *>(out + idx * 4) = u4{l0, h0, l1, h1};
 }
 
+// ---- I2S slots: pico_audio_i2s_multi/audio_i2s_multi.c:217-226 — the same producer words left-justified (<< 8), L then R.
+// 8 bytes in, 8 bytes out per frame: a pure copy-with-shift at memory speed.  Pairs outside `pair_mask` are not touched.
+__global__ __launch_bounds__(256) void i2s_kernel_frames(const int32_t *pairs, uint32_t *out, uint64_t total, uint32_t n_frames, uint32_t n_pairs, uint32_t pair_mask) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;      // (stream * n_pairs + pair) * n_frames + frame
+    if (idx >= total) return;
+    const uint32_t pair = (uint32_t)((idx / n_frames) % n_pairs);
+    if (!((pair_mask >> pair) & 1u)) return;
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    const u2 w = *reinterpret_cast<const u2 *>(pairs + idx * 2);
+    *reinterpret_cast<u2 *>(out + idx * 2) = u2{w.x << 8, w.y << 8};
+}
+// tiled: [tile][output][frame][R] words, R a multiple of 4: one lane per 4 streams of one (output, frame)
+__global__ __launch_bounds__(256) void i2s_kernel_tiled(const int32_t *pairs, uint32_t *out, uint64_t total4, uint64_t plane_words, uint32_t n_out, uint32_t pair_mask) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total4) return;
+    const uint32_t output = (uint32_t)((idx * 4 / plane_words) % n_out);
+    if (!((pair_mask >> (output >> 1)) & 1u)) return;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 w = *reinterpret_cast<const u4 *>(pairs + idx * 4);
+    *reinterpret_cast<u4 *>(out + idx * 4) = u4{w.x << 8, w.y << 8, w.z << 8, w.w << 8};
+}
+
 }  // namespace
+
+hipError_t launch_i2s(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
+                      uint32_t n_wg, uint32_t pair_mask, hipStream_t stream) {
+    if (tiled) {
+        const uint64_t plane = (uint64_t)n_frames * row, total4 = (uint64_t)n_wg * 2 * n_pairs * plane / 4;
+        hipLaunchKernelGGL(i2s_kernel_tiled, dim3((uint32_t)((total4 + 255) / 256)), dim3(256), 0, stream, pairs, out, total4, plane, 2 * n_pairs, pair_mask);
+    } else {
+        const uint64_t total = (uint64_t)n_streams * n_pairs * n_frames;
+        hipLaunchKernelGGL(i2s_kernel_frames, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pairs, out, total, n_frames, n_pairs, pair_mask);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_spdif(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
                         uint32_t n_wg, uint32_t block_pos, uint32_t fs, hipStream_t stream) {

@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
     L.dspi_pdm_modulate.argtypes = [vp, vp, u32, vp, u32]
     L.dspi_pdm_restart.argtypes = [vp, C.c_int32]
     L.dspi_spdif_encode.argtypes = [vp, vp, u32, u32, vp, u32]
+    L.dspi_i2s_encode.argtypes = [vp, vp, u32, u32, vp, u32]
     L.dspi_sync.argtypes = [vp]
     L.dspi_hip_stream.argtypes = [vp]
     L.dspi_hip_stream.restype = vp
@@ -244,6 +245,21 @@ class Dspi:
         nxt = self.L.dspi_spdif_encode(self.h, pairs.ctypes.data, F, block_pos, out.ctypes.data, OUT_TILED if tiled else 0)
         self._ck(min(nxt, 0), "spdif_encode")
         return out, nxt
+
+    def i2s_host(self, pairs: np.ndarray, pair_mask: int = 0, out: np.ndarray | None = None, tiled: bool = False):
+        """I2S slot words (dspi_i2s_encode) on host arrays shaped like the pair words; pair_mask 0 = the slots whose type is I2S.
+        Returns (words, mask encoded); pairs outside the mask keep what `out` held (zeros when not given)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+        F = pairs.shape[2]
+        words = np.zeros(pairs.shape, dtype=np.uint32) if out is None else np.ascontiguousarray(out, dtype=np.uint32)
+        m = self.L.dspi_i2s_encode(self.h, pairs.ctypes.data, F, pair_mask, words.ctypes.data, OUT_TILED if tiled else 0)
+        self._ck(min(m, 0), "i2s_encode")
+        return words, m
+
+    def i2s_device(self, pairs_ptr: int, n_frames: int, pair_mask: int, out_ptr: int, tiled: bool = False) -> int:
+        m = self.L.dspi_i2s_encode(self.h, pairs_ptr, n_frames, pair_mask, out_ptr, MEM_DEVICE | (OUT_TILED if tiled else 0))
+        self._ck(min(m, 0), "i2s_encode")
+        return m
 
     def spdif_device(self, pairs_ptr: int, n_frames: int, block_pos: int, out_ptr: int, tiled: bool = False) -> int:
         nxt = self.L.dspi_spdif_encode(self.h, pairs_ptr, n_frames, block_pos, out_ptr, MEM_DEVICE | (OUT_TILED if tiled else 0))

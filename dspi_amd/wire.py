@@ -125,6 +125,7 @@ REQ = dict(
     SET_LEVELLER_ENABLE=0xB4, GET_LEVELLER_ENABLE=0xB5, SET_LEVELLER_AMOUNT=0xB6, GET_LEVELLER_AMOUNT=0xB7,
     SET_LEVELLER_SPEED=0xB8, GET_LEVELLER_SPEED=0xB9, SET_LEVELLER_MAX_GAIN=0xBA, GET_LEVELLER_MAX_GAIN=0xBB,
     SET_LEVELLER_LOOKAHEAD=0xBC, GET_LEVELLER_LOOKAHEAD=0xBD, SET_LEVELLER_GATE=0xBE, GET_LEVELLER_GATE=0xBF,
+    SET_OUTPUT_TYPE=0xC0, GET_OUTPUT_TYPE=0xC1,
     SET_PREAMP_CH=0xD0, GET_PREAMP_CH=0xD1, SET_MASTER_VOLUME=0xD2, GET_MASTER_VOLUME=0xD3,
     PRESET_SAVE=0x90, PRESET_LOAD=0x91, PRESET_DELETE=0x92, PRESET_GET_NAME=0x93, PRESET_SET_NAME=0x94, PRESET_GET_DIR=0x95,
     PRESET_SET_STARTUP=0x96, PRESET_GET_STARTUP=0x97, PRESET_SET_INCLUDE_PINS=0x98, PRESET_GET_INCLUDE_PINS=0x99, PRESET_GET_ACTIVE=0x9A,

@@ -41,8 +41,8 @@
 extern "C" {
 #endif
 
-#define DSPI_ABI_VERSION 3   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
-                              * dspi_debug_eq_taps (additions only) */
+#define DSPI_ABI_VERSION 4   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
+                              * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1 (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -187,13 +187,23 @@ int dspi_pdm_restart(dspi_ctx *ctx, int32_t stream);
  * block_pos = position of the first frame in the 192-frame channel-status block (0..191).  Returns the position that
  * follows the last frame (>= 0; feed it to the next call) or a negative DSPI_E_*. */
 int dspi_spdif_encode(dspi_ctx *ctx, const int32_t *pairs, uint32_t n_frames, uint32_t block_pos, uint32_t *subframes, uint32_t flags);
+/* ---- I2S slots ----------------------------------------------------------- */
+/* An output slot switched to I2S (REQ_SET_OUTPUT_TYPE 0xC0 / output_types[] of a preset, config.h:286-287) takes the same
+ * words as an S/PDIF slot and left-justifies them into 32-bit I2S slots, L then R, MSB first on the wire
+ * (pico_audio_i2s_multi/audio_i2s_multi.c:217-226: dst = src << 8).
+ *   pairs  int32  [stream][pair][n_frames][2]   exactly what dspi_process wrote        (DSPI_OUT_TILED: [tile][output][n_frames][R])
+ *   words  uint32 [stream][pair][n_frames][2]   same shape; only the pairs in pair_mask (bit p = pair p) are written
+ * pair_mask = DSPI_I2S_PAIRS_BY_TYPE (0): the pairs whose current output type is I2S in stream 0's parameters (the type of a
+ * slot is a property of the device, like the sample rate).  Returns the mask that was encoded (>= 0) or a negative DSPI_E_*. */
+#define DSPI_I2S_PAIRS_BY_TYPE 0u
+int dspi_i2s_encode(dspi_ctx *ctx, const int32_t *pairs, uint32_t n_frames, uint32_t pair_mask, uint32_t *words, uint32_t flags);
 /* the HIP stream (hipStream_t) the context launches on, for event timing by the caller */
 void *dspi_hip_stream(dspi_ctx *ctx);
 
 /* ---- status ------------------------------------------------------------------------------ */
 /* REQ_GET_STATUS wValue 9: peaks[C] LE u16, cpu0, cpu1 (always 0 here), clip_flags LE u16 = 26 / 18 bytes */
 int dspi_get_status(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
-/* REQ_CLEAR_CLIPS: returns the flags that were set */
+/* REQ_CLEAR_CLIPS: returns the flags that were set (DSPI_ALL_STREAMS: clears every stream, returns stream 0's flags) */
 int dspi_clear_clips(dspi_ctx *ctx, int32_t stream);
 
 /* ---- introspection for tests (host-side derived parameter image of a stream) ------------ */

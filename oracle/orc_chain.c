@@ -1161,6 +1161,7 @@ int orc_load_preset_slot(orc_ctx *c, const void *image, uint32_t len, int expect
     int rc = PRESET_OK;
     if (!ok) { c->preset_loading = false; rc = PRESET_ERR_CRC; }
     else {
+        uint8_t old_types[NUM_SPDIF_INSTANCES]; memcpy(old_types, c->output_types, NUM_SPDIF_INSTANCES);   /* main.c:934-935 */
         apply_slot_to_live(c, &s, c->dir_include_pins != 0);
         apply_master_volume_from_mode(c, &s);
         float fs = (float)c->audio_state.freq;
@@ -1171,6 +1172,8 @@ int orc_load_preset_slot(orc_ctx *c, const void *image, uint32_t len, int expect
          * re-arms the mute for flash_mute_hold_samples() = max(10 ms, 512 samples) (:262-266, :349-350) — the hold after a
          * preset load is that, not PRESET_MUTE_SAMPLES (found by running the firmware build, tests/test_oracle_vs_fw.py) */
         prepare_pipeline_reset(c, flash_mute_hold_samples_(c->audio_state.freq));
+        /* a slot type that changed goes through process_type_switches: prepare_pipeline_reset once more (main.c:957-972, :279) */
+        if (memcmp(old_types, c->output_types, NUM_SPDIF_INSTANCES) != 0) prepare_pipeline_reset(c, PRESET_MUTE_SAMPLES);
         service(c);
     }
     orc_leave(csr);
@@ -1465,6 +1468,18 @@ int orc_vendor_get(orc_ctx *c, uint8_t req, uint16_t wValue, void *buf, uint16_t
         case REQ_GET_CHANNEL_NAME: return idx < NUM_CHANNELS ? put(buf, cap, c->channel_names[idx], PRESET_NAME_LEN) : -1;
         case REQ_GET_ALL_PARAMS: if (cap < sizeof(WireBulkParams)) return -2; return orc_collect_bulk(c, buf);
         case REQ_FACTORY_RESET: orc_factory_defaults(c); u8 = 0; return put(buf, cap, &u8, 1);
+        case REQ_SET_OUTPUT_TYPE: { /* usb_audio.c:2984-3016 + the deferred switch, main.c:1110-1121 -> :230-424: what the audio
+                                     * path sees of it is prepare_pipeline_reset (:279) and the new type */
+            uint8_t slot = wValue & 0xFF, type = (wValue >> 8) & 0xFF;
+            if (slot >= NUM_SPDIF_INSTANCES) u8 = PIN_CONFIG_INVALID_OUTPUT;
+            else if (type > 1) u8 = PIN_CONFIG_INVALID_PIN;
+            else {
+                u8 = PIN_CONFIG_SUCCESS;
+                if (type != c->output_types[slot]) { c->output_types[slot] = type; prepare_pipeline_reset(c, PRESET_MUTE_SAMPLES); }
+            }
+            return put(buf, cap, &u8, 1);
+        }
+        case REQ_GET_OUTPUT_TYPE: return idx < NUM_SPDIF_INSTANCES ? put(buf, cap, &c->output_types[idx], 1) : -1;
         default: return -1;
     }
 }

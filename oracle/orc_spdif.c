@@ -82,3 +82,15 @@ uint32_t orc_spdif_encode(const int32_t *pair, uint32_t n, uint32_t block_pos, u
     }
     return block_pos;
 }
+
+/* ---- I2S slots (pico_audio_i2s_multi/audio_i2s_multi.c:178-243) -------------------------------------------------------
+ * An output slot whose type is OUTPUT_TYPE_I2S (config.h:286-287, output_types[]) takes the same producer words and
+ * left-justifies them: dst = src << 8 for L and R (:223-226), MSB first on the wire, low byte zero.  The consumer-buffer
+ * slicing around it (:206-238) is transport: completed buffers back to back are the input order.
+ * pair: [n][2] int32; out: [n][2] uint32.  Pinned by _ref/libref_i2s.so (ref_i2s.c), tests/test_oracle_spdif.py. */
+void orc_i2s_frames(const int32_t *pair, uint32_t n, uint32_t *out) {
+    for (uint32_t i = 0; i < n; i++) {
+        out[i * 2] = (uint32_t)pair[i * 2] << 8;
+        out[i * 2 + 1] = (uint32_t)pair[i * 2 + 1] << 8;
+    }
+}

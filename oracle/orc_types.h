@@ -220,9 +220,13 @@ enum {
     REQ_SET_LEVELLER_ENABLE = 0xB4, REQ_GET_LEVELLER_ENABLE, REQ_SET_LEVELLER_AMOUNT, REQ_GET_LEVELLER_AMOUNT,
     REQ_SET_LEVELLER_SPEED, REQ_GET_LEVELLER_SPEED, REQ_SET_LEVELLER_MAX_GAIN, REQ_GET_LEVELLER_MAX_GAIN,
     REQ_SET_LEVELLER_LOOKAHEAD, REQ_GET_LEVELLER_LOOKAHEAD, REQ_SET_LEVELLER_GATE, REQ_GET_LEVELLER_GATE,
+    REQ_SET_OUTPUT_TYPE = 0xC0, REQ_GET_OUTPUT_TYPE = 0xC1,      /* config.h:192-193 */
     REQ_SET_PREAMP_CH = 0xD0, REQ_GET_PREAMP_CH, REQ_SET_MASTER_VOLUME, REQ_GET_MASTER_VOLUME,
     REQ_SET_MASTER_VOLUME_MODE, REQ_GET_MASTER_VOLUME_MODE, REQ_SAVE_MASTER_VOLUME, REQ_GET_SAVED_MASTER_VOLUME,
 };
+
+/* pin / output-type request status (config.h:278-287) */
+enum { PIN_CONFIG_SUCCESS = 0, PIN_CONFIG_INVALID_PIN = 1, PIN_CONFIG_INVALID_OUTPUT = 3, OUTPUT_TYPE_SPDIF = 0, OUTPUT_TYPE_I2S = 1 };
 
 /* ---- integer helpers (Q28 flavour) -------------------------------------------------- */
 #if !PICO_RP2350

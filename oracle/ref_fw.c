@@ -215,8 +215,11 @@ static void fw_service(void) { /* main.c:738-1162, the branches that touch the D
     if (stream_restart_resync_pending) { stream_restart_resync_pending = false; fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES); }
     if (preset_load_pending) { /* :926-976 */
         preset_load_pending = false;
+        uint8_t old_types[NUM_SPDIF_INSTANCES]; memcpy(old_types, output_types, NUM_SPDIF_INSTANCES);
         fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES);
         fw_last_preset_status = preset_load(pending_preset_load_slot);
+        /* :957-972: changed slot types go through process_type_switches (:230-424), whose audio-path effect is :279 */
+        if (memcmp(old_types, output_types, NUM_SPDIF_INSTANCES) != 0) fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES);
     }
     if (save_params_pending) { save_params_pending = false; fw_prepare_flash_write(); flash_save_params(); }
     if (preset_save_pending) { preset_save_pending = false; fw_prepare_flash_write(); fw_last_preset_status = preset_save(pending_preset_save_slot); }
@@ -235,9 +238,17 @@ static void fw_service(void) { /* main.c:738-1162, the branches that touch the D
         memset(delay_lines, 0, sizeof(delay_lines));
         fw_transition_core1();
     }
-    if (output_type_change_mask) { /* :1110-1121: only the stored type matters to the blobs */
+    if (output_type_change_mask) { /* :1110-1121 -> process_type_switches :230-424: the hardware part is not modelled; the audio
+                                    * path sees prepare_pipeline_reset (:279, only when a type really changes, :260-266) and :398 */
         uint8_t mask = output_type_change_mask; output_type_change_mask = 0;
-        for (int i = 0; i < NUM_SPDIF_INSTANCES; i++) if (mask & (1u << i)) output_types[i] = pending_output_types[i];
+        bool any = false;
+        for (int i = 0; i < NUM_SPDIF_INSTANCES; i++)
+            if ((mask & (1u << i)) && pending_output_types[i] <= OUTPUT_TYPE_I2S && pending_output_types[i] != output_types[i]) any = true;
+        if (any) {
+            fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES);
+            for (int i = 0; i < NUM_SPDIF_INSTANCES; i++)
+                if ((mask & (1u << i)) && pending_output_types[i] <= OUTPUT_TYPE_I2S) output_types[i] = pending_output_types[i];
+        }
     }
     if (bulk_params_pending) { /* :1126-1162 */
         bulk_params_pending = false;

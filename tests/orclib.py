@@ -274,3 +274,27 @@ def spdif_encode(pair_words: np.ndarray, block_pos: int, fs: int, ref: bool = Fa
     out = np.zeros((x.shape[0], 4), dtype=np.uint32)
     nxt = L.orc_spdif_encode(x.ctypes.data_as(C.c_void_p), C.c_uint32(x.shape[0]), C.c_uint32(block_pos), C.c_uint32(fs), out.ctypes.data_as(C.c_void_p))
     return out, int(nxt)
+
+
+def i2s_ref_available() -> bool:
+    return (ORC_DIR / "_ref" / "libref_i2s.so").exists()
+
+
+def i2s_frames(pair_words: np.ndarray) -> np.ndarray:
+    """oracle/orc_spdif.c:orc_i2s_frames — int32 [frames][2] -> uint32 [frames][2], the words an I2S slot shifts out."""
+    _build()
+    L = C.CDLL(str(ORC_DIR / "liborc_spdif.so"), mode=os.RTLD_LOCAL)
+    x = np.ascontiguousarray(pair_words, dtype=np.int32)
+    out = np.zeros((x.shape[0], 2), dtype=np.uint32)
+    L.orc_i2s_frames(x.ctypes.data_as(C.c_void_p), C.c_uint32(x.shape[0]), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def i2s_ref_give(pair_words: np.ndarray, packet: int, consumer_len: int) -> np.ndarray:
+    """the reference's i2s_wrap_producer_give (oracle/ref_i2s.c) fed in packets: completed consumer buffers back to back"""
+    L = C.CDLL(str(ORC_DIR / "_ref" / "libref_i2s.so"), mode=os.RTLD_LOCAL)
+    L.orc_i2s_ref_give.restype = C.c_uint32
+    x = np.ascontiguousarray(pair_words, dtype=np.int32)
+    out = np.zeros((x.shape[0], 2), dtype=np.uint32)
+    n = L.orc_i2s_ref_give(x.ctypes.data_as(C.c_void_p), C.c_uint32(x.shape[0]), C.c_uint32(packet), C.c_uint32(consumer_len), out.ctypes.data_as(C.c_void_p))
+    return out[:n]

@@ -121,7 +121,6 @@ def test_vendor_requests_between_launches(flavor):
     fs, B = 48000, 48
     S = 4
     d = Dspi(flavor, S, device=0); o = [Oracle(flavor, detmath=True) for _ in range(S)]
-    pcm = WL.synth_pcm16(S, B * 72, fs)
     R = W.REQ
     f = lambda v: struct.pack("<f", v)
     steps = [
@@ -139,8 +138,22 @@ def test_vendor_requests_between_launches(flavor):
         # (usb_audio.c:930-933), the meters still see the tail
         lambda x: (x.vendor_set(R["SET_OUTPUT_ENABLE"], 2, b"\x00"), x.vendor_set(R["SET_OUTPUT_ENABLE"], 3, b"\x00")),
         lambda x: x.vendor_set(R["SET_OUTPUT_ENABLE"], 3, b"\x01"),
+        # a preset load that fails its CRC drops the mute it had armed (flash_storage.c:806) ...
+        lambda x: x.load_slot(bad_image),
+        # ... and a failed load followed, before the next packet, by a request that arms the mute again: the second one wins
+        lambda x: (x.load_slot(bad_image), x.load_bulk(WL.full_chain_blob(flavor))),
+        lambda x: (x.load_slot(bad_image), x.load_slot(slot_image)),
+        # output slot 1 becomes I2S (REQ_SET_OUTPUT_TYPE, usb_audio.c:2984-3016): the switch mutes the pipeline (main.c:279)
+        lambda x: set_type(x, 0x0101),
+        lambda x: set_type(x, 0x0101),                              # no-op: no mute
+        # a preset whose slot types differ from the live ones: the type switch re-arms the mute after the flash hold (main.c:957-972)
+        lambda x: x.load_slot(slot_image),
+        lambda x: x.load_slot(slot_image),                          # same types now: the flash hold stands
     ]
+    set_type = lambda x, wv: x.vendor_get(R["SET_OUTPUT_TYPE"], wv, 1, -1) if isinstance(x, Dspi) else x.vendor_get(R["SET_OUTPUT_TYPE"], wv, 1)
     ref = Oracle(flavor); ref.load_bulk(WL.full_chain_blob(flavor)); slot_image = ref.save_slot(0)
+    bad_image = bytearray(slot_image); bad_image[200] ^= 0x40; bad_image = bytes(bad_image)
+    pcm = WL.synth_pcm16(S, B * 6 * len(steps), fs)
     for k, step in enumerate(steps):
         step(d)
         for oo in o: step(oo)
@@ -173,6 +186,11 @@ def test_per_stream_presets_and_clip_flags():
     flags = int.from_bytes(d.status(19)[-2:], "little")          # stream class 19 = full-scale square
     assert flags != 0 and d.clear_clips(19) == flags and int.from_bytes(d.status(19)[-2:], "little") == 0
     assert int.from_bytes(d.status(18)[-2:], "little") == int.from_bytes(o[18].status()[-2:], "little")
+    # DSPI_ALL_STREAMS: every stream's sticky flags go, whatever stream 0 held (it held none here)
+    pairs, sub, peaks = d.process_host(pcm[:, :B * 4], 4, B)
+    assert int.from_bytes(d.status(0)[-2:], "little") == 0 and int.from_bytes(d.status(19)[-2:], "little") != 0
+    assert d.clear_clips() == 0
+    assert all(int.from_bytes(d.status(s)[-2:], "little") == 0 for s in range(S))
     d.close()
 
 
@@ -406,6 +424,41 @@ def test_spdif_subframes(flavor):
                     assert n2 == nxt and np.array_equal(ref, sf[s_, p_]), (fs, c, s_, p_)
             pos = nxt
         d.close(); dt.close()
+
+
+@pytest.mark.parametrize("flavor", [1, 0])
+def test_i2s_slot_words(flavor):
+    """slots switched to I2S (REQ_SET_OUTPUT_TYPE) take the chain's pair words left-justified (dspi_i2s_encode,
+    audio_i2s_multi.c:217-226): bit-exact against the oracle (pinned to the reference's producer-give), both layouts; only the
+    selected pairs are written; DSPI_I2S_PAIRS_BY_TYPE follows output_types[] (explicit mask otherwise)."""
+    B, blocks, fs = 45, 7, 44100                    # 315 frames: odd count (the stream-major kernel works per frame)
+    S = 140 if flavor else 70
+    P = 4 if flavor else 2
+    d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-3 * 256); assert d.load_bulk(WL.full_chain_blob(flavor)) == 0
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    words, m = d.i2s_host(np.zeros((S, P, B, 2), dtype=np.int32))
+    assert m == 0 and not words.any()                                        # every slot is S/PDIF: nothing to encode
+    assert d.vendor_get(W.REQ["SET_OUTPUT_TYPE"], 0x0101, 1, -1) == b"\x00"
+    pairs, _, _ = d.process_host(pcm, blocks, B)                              # (the switch's mute envelope is in these words)
+    F = pairs.shape[2]
+    keep = np.full(pairs.shape, 0xDEADBEEF, dtype=np.uint32)
+    words, m = d.i2s_host(pairs, out=keep.copy())
+    assert m == 0b10
+    for s_ in range(S):
+        assert np.array_equal(words[s_, 1], orclib.i2s_frames(pairs[s_, 1])), s_
+    assert np.array_equal(np.delete(words, 1, axis=1), np.delete(keep, 1, axis=1))
+    full, m = d.i2s_host(pairs, pair_mask=(1 << P) - 1)
+    assert m == (1 << P) - 1 and np.array_equal(full, pairs.view(np.uint32) << 8)
+    R = d.tile_streams(); nt = (S + R - 1) // R
+    pt = np.zeros((nt * R, 2 * P, F), dtype=np.int32)
+    pt[:S] = pairs.transpose(0, 1, 3, 2).reshape(S, 2 * P, F)
+    pt = np.ascontiguousarray(pt.reshape(nt, R, 2 * P, F).transpose(0, 2, 3, 1))         # [tile][output][frame][R]
+    wt, m = d.i2s_host(pt, tiled=True)
+    assert m == 0b10
+    wt = wt.transpose(0, 3, 1, 2).reshape(nt * R, P, 2, F).transpose(0, 1, 3, 2)[:S]
+    assert np.array_equal(wt[:, 1], words[:, 1]) and not wt[:, 0].any()
+    assert d.L.dspi_i2s_encode(d.h, pairs.ctypes.data, F, 1 << P, words.ctypes.data, 0) == -10    # DSPI_E_INVAL: no such pair
+    d.close()
 
 
 def test_per_band_taps_both_contracts():

@@ -169,7 +169,11 @@ def test_vendor_requests_match_oracle(product_lib, flavor, fma):
             if req in (0xA0, 0x53, 0x50, 0x83, 0xD6):
                 continue
             assert a == b, (hex(req), wv)
-    assert d.vendor_set(0xC0, 0, b"\x01") == -14 and o.vendor_set(0xC0, 0, b"\x01") == -1      # I2S/pin/flash requests: unsupported
+    for wv in (0x0101, 0x0101, 0x0200, 0x0107, 0x0100, 0x0001):      # REQ_SET_OUTPUT_TYPE answers on the IN side (usb_audio.c:2984-3016)
+        assert d.vendor_get(R["SET_OUTPUT_TYPE"], wv, 1) == o.vendor_get(R["SET_OUTPUT_TYPE"], wv, 1), hex(wv)
+        assert [d.vendor_get(R["GET_OUTPUT_TYPE"], i, 1) for i in range(5)] == [o.vendor_get(R["GET_OUTPUT_TYPE"], i, 1) for i in range(5)]
+        check_against_oracle(d, o, flavor)
+    assert d.vendor_set(0xC0, 0, b"\x01") == -14 and o.vendor_set(0xC0, 0, b"\x01") == -1      # the OUT direction of 0xC0 does not exist; pin / flash requests: unsupported
     assert d.vendor_get(W.REQ["GET_ALL_PARAMS"], 0, 4096) == o.collect_bulk()
 
 

@@ -46,3 +46,20 @@ def test_structure_preambles_parity_channel_status():
             assert (sum(bits[:27]) + p) % 2 == 0                                # even parity over slots 4-31
         # first cell of every data slot is 1 (the table's 0x5555 pattern)
         assert (int(out[i, 0]) >> 8) & 0x555555 == 0x555555 and int(out[i, 1]) & 0x55555555 == 0x55555555
+
+
+def test_i2s_restatement_matches_the_reference_producer_give():
+    """orc_i2s_frames against the reference's own i2s_wrap_producer_give (audio_i2s_multi.c:198-243, compiled in place): packets of
+    every length the firmware sees, consumer buffers that do and do not divide them; whole consumer buffers come out."""
+    if not orclib.i2s_ref_available():
+        pytest.skip("oracle/_ref/libref_i2s.so not built (needs /root/reference)")
+    rng = np.random.default_rng(11)
+    x = rng.integers(-(1 << 23), 1 << 23, size=(2000, 2), dtype=np.int64).astype(np.int32)
+    x[:6] = [[0, 0], [0x7FFFFF, -0x800000], [-1, 1], [0x555555, -0x2AAAAB], [1, 2], [0x123456, -0x123456]]
+    want = orclib.i2s_frames(x)
+    assert np.array_equal(want[:6, 0], np.array([0, 0x7FFFFF00, 0xFFFFFF00, 0x55555500, 0x100, 0x12345600], dtype=np.uint32))
+    assert not (want & 0xFF).any()
+    for packet, consumer in ((48, 48), (96, 48), (45, 48), (44, 192), (1, 7), (97, 64)):
+        got = orclib.i2s_ref_give(x, packet, consumer)
+        assert len(got) == (2000 // consumer) * consumer
+        assert np.array_equal(got, want[:len(got)])

@@ -334,6 +334,43 @@ def test_preset_save_load_delete_through_vendor_requests(flavor):
     assert fw.vendor_get(W.REQ["PRESET_GET_ACTIVE"], 0, 1) == b"\x06"
 
 
+@pytest.mark.parametrize("flavor", [1, 0])
+def test_output_type_switches(flavor):
+    """REQ_SET_OUTPUT_TYPE / GET (usb_audio.c:2984-3026) and a preset whose slot types differ from the live ones: the handler is
+    the reference's, the deferred switch (main.c:230-424) is restated on both sides (its audio-path effect is the mute,
+    main.c:279; a preset load that changes a type re-arms it with PRESET_MUTE_SAMPLES after the flash hold, main.c:957-972).
+    The saved sector carries the types (flash_storage.c:522-529)."""
+    R = W.REQ
+    fw = Oracle(flavor, ref="fw"); o = Oracle(flavor, x86_casts=True)
+    P = 4 if flavor else 2
+    for x in (fw, o):
+        assert x.set_rate(48000) == 0 and x.load_bulk(WL.full_chain_blob(flavor)) == 0
+    same_audio(o, fw, signal(48, 20, 48000, 3, 16), 20, 48, 16, "before")
+    for wv in (0x0101, 0x0101, 0x0200, (1 << 8) | P, 0x0001 if False else 0x0100):      # switch, no-op, bad type, bad slot, slot 0
+        assert fw.vendor_get(R["SET_OUTPUT_TYPE"], wv, 1) == o.vendor_get(R["SET_OUTPUT_TYPE"], wv, 1), hex(wv)
+        for slot in range(P + 1):
+            assert fw.vendor_get(R["GET_OUTPUT_TYPE"], slot, 1) == o.vendor_get(R["GET_OUTPUT_TYPE"], slot, 1)
+        same_state(o, fw, hex(wv))
+        same_audio(o, fw, signal(48, 3, 48000, 5, 16), 3, 48, 16, hex(wv))       # 144 frames: inside the 256-sample mute
+        same_audio(o, fw, signal(48, 12, 48000, 6, 16), 12, 48, 16, hex(wv))
+    assert o.vendor_get(R["GET_OUTPUT_TYPE"], 1, 1) == b"\x01" and o.vendor_get(R["GET_OUTPUT_TYPE"], 0, 1) == b"\x01"
+    # save with slots 0 and 1 = I2S, go back to S/PDIF, load: the types come back and the mute is the type switch's
+    assert fw.vendor_get(R["PRESET_SAVE"], 2, 1) == b"\x00"
+    sector = fw.read_flash()[(1 + 2) * 4096:(1 + 2) * 4096 + len(o.save_slot(2))]
+    assert sector == o.save_slot(2)
+    for wv in (0x0000, 0x0001):
+        assert fw.vendor_get(R["SET_OUTPUT_TYPE"], wv, 1) == o.vendor_get(R["SET_OUTPUT_TYPE"], wv, 1) == b"\x00"
+    same_audio(o, fw, signal(48, 12, 48000, 7, 16), 12, 48, 16, "back to S/PDIF")
+    assert fw.vendor_get(R["PRESET_LOAD"], 2, 1) == b"\x00" and o.load_slot(sector, 2) == 0
+    assert o.vendor_get(R["GET_OUTPUT_TYPE"], 1, 1) == fw.vendor_get(R["GET_OUTPUT_TYPE"], 1, 1) == b"\x01"
+    same_state(o, fw, "types from the preset")
+    same_audio(o, fw, signal(48, 16, 48000, 8, 16), 16, 48, 16, "types from the preset")
+    # the same preset again: no type changes, the flash hold stands
+    assert fw.vendor_get(R["PRESET_LOAD"], 2, 1) == b"\x00" and o.load_slot(sector, 2) == 0
+    same_state(o, fw, "same types")
+    same_audio(o, fw, signal(48, 16, 48000, 9, 16), 16, 48, 16, "same types")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # pdm_generator.c: the sigma-delta modulator (pdm_processing_loop, run as a coroutine inside the firmware build)
 # ---------------------------------------------------------------------------------------------------------------------
