@@ -183,8 +183,9 @@ def chain_workload(name):
         return dict(flavor=0, fs=48000, B=48, streams=16384, blocks=50, channels=7, vol=-20 * 256, blob=WL.full_chain_blob(0),
                     text="BASELINE config 5: RP2040 Q28 fixed-point 7-channel chain (5 outputs, delays <= 40 ms), 16 384 streams, 48 kHz, 48-frame packets")
     if name == "perstream":
-        return dict(flavor=1, fs=96000, B=96, streams=16384, blocks=25, channels=11, vol=-20 * 256, blob=WL.full_chain_blob(1), perstream=True,
-                    text="SURVEY 8f-1: config-3 chain, every stream its own preset (one parameter image per stream, per-lane-parameter kernel)")
+        return dict(flavor=1, fs=96000, B=96, streams=65536, blocks=50, channels=11, vol=-20 * 256, blob=WL.full_chain_blob(1), perstream=True,
+                    text="SURVEY 8f-1: config 3 with 65 536 DISTINCT presets of one structure (one parameter image per stream; packed kernel with per-lane "
+                         "values read from value tiles)")
     raise SystemExit(f"unknown config {name}")
 
 
@@ -390,11 +391,10 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
              "binds": "valu"}
         return r
 
-    if flavor == 1 and not w.get("perstream"):
-        kname = "chain_kernel_pk<false, true, false, %s, %s>" % ("true" if args.out_layout == "tiled" else "false", "true" if args.contract == "fma" else "false")
+    if flavor == 1:
+        kname = "chain_kernel_pk<false, true, false, %s, %s, %s>" % ("true" if args.out_layout == "tiled" else "false", "true" if args.contract == "fma" else "false",
+                                                                     "true" if w.get("perstream") else "false")
         if CH == 2: kname = kname.replace("<false, true", "<false, false")
-    elif flavor == 1:
-        kname = "chain_kernel<1, false, false, %s>" % ("true" if args.contract == "fma" else "false")
     else:
         kname = "chain_kernel<0, false, false, false>"
     roofline = roof(primary)

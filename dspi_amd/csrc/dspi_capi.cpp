@@ -51,6 +51,18 @@ struct dspi_ctx {
     uint32_t *d_xwords = nullptr; size_t d_xwords_cap = 0;      // exchange area of the packed kernel's copy wave (stream-major output)
     DevImage *d_images = nullptr;
     std::vector<uint32_t> image_flags;             // DevImage::flags of each uploaded image (kernel variant selection)
+    // float flavour, per-lane VALUES: a row whose streams carry several presets of one structure runs the packed kernel with
+    // its numbers in a value tile (dspi_image.h); ImageSig = what has to agree for that
+    struct ImageSig {
+        uint32_t flags, ch_bypassed, out_enabled, out_mute, fs_hz, mute_transition, mix_nz;
+        int32_t delay[kMaxOut];
+        uint8_t kinds[kPvBandSlots];
+    };
+    std::vector<ImageSig> image_sig;
+    std::vector<uint8_t> row_pv;                   // [n_wg] the row is a per-lane-value row
+    std::vector<uint8_t> image_touched;            // images uploaded since the tiles were last built
+    float *d_vals = nullptr; size_t d_vals_cap = 0;
+    uint32_t *d_pv_rows = nullptr; size_t d_pv_rows_cap = 0;
     size_t d_images_cap = 0;
     WgItem *d_items = nullptr;
     size_t d_items_cap = 0;
@@ -155,15 +167,32 @@ int rebuild_assignment(dspi_ctx *c) {
         for (size_t i = 0; i < ni; i++) { c->image_item_offset[k][i] = (uint32_t)total; total += c->image_items[k][i].size(); }
     int rc = ensure(c, c->d_items, c->d_items_cap, total * sizeof(WgItem));
     if (rc) return rc;
-    for (int k = 0; k < 4; k++)
-        for (size_t i = 0; i < ni; i++)
-            if (!c->image_items[k][i].empty())
-                HIPCK(c, hipMemcpyAsync(c->d_items + c->image_item_offset[k][i], c->image_items[k][i].data(), c->image_items[k][i].size() * sizeof(WgItem),
-                                        hipMemcpyHostToDevice, c->hs));
-    HIPCK(c, hipStreamSynchronize(c->hs));
+    HIPCK(c, hipStreamSynchronize(c->hs));      // no state_ops launch may still be reading the list
+    {   // one upload (per-stream presets: tens of thousands of one-item lists)
+        std::vector<WgItem> all;
+        all.reserve(total);
+        for (int k = 0; k < 4; k++)
+            for (size_t i = 0; i < ni; i++) all.insert(all.end(), c->image_items[k][i].begin(), c->image_items[k][i].end());
+        if (!all.empty()) HIPCK(c, hipMemcpy(c->d_items, all.data(), all.size() * sizeof(WgItem), hipMemcpyHostToDevice));
+    }
     c->assignment_dirty = false;
     c->launch_dirty = true;
     return 0;
+}
+
+dspi_ctx::ImageSig make_sig(const DevImage &img) {
+    dspi_ctx::ImageSig g;
+    memset(&g, 0, sizeof g);
+    g.flags = img.flags; g.ch_bypassed = img.ch_bypassed; g.out_enabled = img.out_enabled; g.out_mute = img.out_mute;
+    g.fs_hz = img.fs_hz; g.mute_transition = img.mute_transition;
+    for (int o = 0; o < kMaxOut; o++) {
+        g.delay[o] = img.delay_samples[o];
+        if (img.mix[0][o].f != 0.0f) g.mix_nz |= 1u << o;
+        if (img.mix[1][o].f != 0.0f) g.mix_nz |= 1u << (kMaxOut + o);
+    }
+    for (int ch = 0; ch < kMaxCh; ch++) for (int b = 0; b < kBands; b++) g.kinds[ch * kBands + b] = (uint8_t)img.eq[ch][b].kind;
+    g.kinds[kMaxCh * kBands] = (uint8_t)img.loud[0].kind; g.kinds[kMaxCh * kBands + 1] = (uint8_t)img.loud[1].kind;
+    return g;
 }
 
 int rebuild_launch_lists(dspi_ctx *c) {
@@ -172,11 +201,31 @@ int rebuild_launch_lists(dspi_ctx *c) {
     // second stream, WgItem::image = which; Q28: rows holding several images): the per-lane parameter kernels read every
     // lane's own image, so all images of a row merge into one item.  Launch list 3 stays empty.
     size_t total = 0;
+    // float: rows holding several images of ONE structure -> per-lane-value rows (launch list 3, packed kernel + value tile)
+    struct RowAcc { uint64_t m0 = 0, m1 = 0; int n = 0; uint32_t first = 0; bool same = true; };
+    std::map<uint32_t, RowAcc> rows_f;
+    c->row_pv.assign(c->n_wg, 0);
+    if (c->flavor && c->image_sig.size() >= c->images.size()) {
+        for (size_t i = 0; i < c->images.size(); i++)
+            for (const WgItem &it : c->image_items[0][i]) {
+                RowAcc &r = rows_f[it.wg];
+                if (r.n++ == 0) r.first = (uint32_t)i;
+                else if (memcmp(&c->image_sig[r.first], &c->image_sig[i], sizeof(dspi_ctx::ImageSig)) != 0) r.same = false;
+                r.m0 |= it.mask; r.m1 |= it.mask1;
+            }
+        for (const auto &r : rows_f) if (r.second.n > 1 && r.second.same && (r.second.m0 & r.second.m1)) c->row_pv[r.first] = 1;
+    }
     for (int lev = 0; lev < 2; lev++)
         for (int k = 0; k < 4; k++) {
             auto &v = c->launch_items[lev][k];
             v.clear();
-            if (k >= 2) {
+            if (k == 3) {
+                for (const auto &r : rows_f) {
+                    if (!c->row_pv[r.first]) continue;
+                    const int ilev = (c->image_flags[r.second.first] & IF_LEVELLER_ON) ? 1 : 0;
+                    if (ilev == lev) v.push_back(WgItem{r.first, r.second.first, r.second.m0 & r.second.m1, 0ull});
+                }
+            } else if (k >= 2) {
                 // float: lanes with one stream of an image (k = 2 first, 3 second stream); Q28 (k = 2): rows that hold
                 // several images.  Per-lane parameter kernel: all images of a row merge into one item.
                 // Float: both lane components go into list 2 (WgItem::image = component), one launch.
@@ -186,7 +235,16 @@ int rebuild_launch_lists(dspi_ctx *c) {
                         const int src = c->flavor ? 2 + comp : 0;
                         for (size_t i = 0; i < c->images.size(); i++)
                             if (c->image_refs[i] > 0)
-                                for (const WgItem &it : c->image_items[src][i]) { auto &r = rows[it.wg]; r.first |= it.mask; r.second++; }
+                                for (const WgItem &it : c->image_items[src][i]) {
+                                    if (c->flavor && c->row_pv[it.wg]) continue;      // per-lane-value row: only its half-filled lanes come here (below)
+                                    auto &r = rows[it.wg]; r.first |= it.mask; r.second++;
+                                }
+                        if (c->flavor)
+                            for (const auto &rf : rows_f) {
+                                if (!c->row_pv[rf.first]) continue;
+                                const uint64_t only = comp ? (rf.second.m1 & ~rf.second.m0) : (rf.second.m0 & ~rf.second.m1);
+                                if (only) { auto &r = rows[rf.first]; r.first |= only; r.second++; }
+                            }
                         for (const auto &r : rows)
                             if (c->flavor || r.second.second > 1) v.push_back(WgItem{r.first, (uint32_t)comp, r.second.first, 0ull});
                     }
@@ -203,6 +261,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
                     if (ilev != lev) continue;
                     for (WgItem it : c->image_items[k][i]) {
                         if (!c->flavor && k == 0 && per_row[it.wg] > 1) continue;
+                        if (c->flavor && k == 1 && c->row_pv[it.wg]) continue;
                         it.image = (uint32_t)i; v.push_back(it);
                     }
                 }
@@ -220,6 +279,8 @@ int rebuild_launch_lists(dspi_ctx *c) {
                 HIPCK(c, hipMemcpy(c->d_litems + c->launch_item_offset[lev][k], c->launch_items[lev][k].data(),
                                    c->launch_items[lev][k].size() * sizeof(WgItem), hipMemcpyHostToDevice));
     HIPCK(c, hipMemcpy(c->d_stream_image, c->stream_image.data(), (size_t)c->n_streams * 4, hipMemcpyHostToDevice));
+    // every per-lane-value row gets its tile rebuilt (commit_params)
+    for (size_t i = 0; i < c->image_touched.size(); i++) c->image_touched[i] = 1;
     c->launch_dirty = false;
     return 0;
 }
@@ -247,6 +308,10 @@ int commit_params(dspi_ctx *c) {
     }
     // dirty images go up in contiguous runs (per-stream presets dirty thousands at once)
     if (c->image_flags.size() < ni) c->image_flags.resize(ni, 0u);
+    if (c->flavor && c->image_sig.size() < ni) {
+        dspi_ctx::ImageSig none; memset(&none, 0xff, sizeof none);
+        c->image_sig.resize(ni, none); c->image_touched.resize(ni, 1); c->launch_dirty = true;
+    }
     std::vector<DevImage> run;
     size_t run0 = 0;
     auto flush = [&]() -> int {
@@ -262,6 +327,11 @@ int commit_params(dspi_ctx *c) {
         p.build_image(run.back());
         if ((c->image_flags[i] ^ run.back().flags) & IF_LEVELLER_ON) c->launch_dirty = true;
         c->image_flags[i] = run.back().flags;
+        if (c->flavor) {
+            const dspi_ctx::ImageSig sig = make_sig(run.back());
+            if (memcmp(&sig, &c->image_sig[i], sizeof sig) != 0) { c->image_sig[i] = sig; c->launch_dirty = true; }
+            c->image_touched[i] = 1;
+        }
         p.dirty = false;
     }
     { int rc = flush(); if (rc) return rc; }
@@ -280,6 +350,24 @@ int commit_params(dspi_ctx *c) {
         i = j;
     }
     if (c->launch_dirty) { int rc = rebuild_launch_lists(c); if (rc) return rc; }
+    if (c->flavor) {       // value tiles of the per-lane-value rows that hold an image uploaded above
+        std::vector<uint32_t> rows;
+        std::vector<uint8_t> seen(c->n_wg, 0);
+        for (size_t i = 0; i < ni; i++) {
+            if (!c->image_touched[i]) continue;
+            c->image_touched[i] = 0;
+            for (const WgItem &it : c->image_items[0][i])
+                if (c->row_pv[it.wg] && !seen[it.wg]) { seen[it.wg] = 1; rows.push_back(it.wg); }
+        }
+        if (!rows.empty()) {
+            int rc = ensure(c, c->d_vals, c->d_vals_cap, (size_t)c->n_wg * kPvTileFloats * sizeof(float));
+            if (rc) return rc;
+            if ((rc = ensure(c, c->d_pv_rows, c->d_pv_rows_cap, (size_t)c->n_wg * 4))) return rc;
+            HIPCK(c, hipStreamSynchronize(c->hs));      // no launch may still be reading the tiles or the row list
+            HIPCK(c, hipMemcpy(c->d_pv_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+            HIPCK(c, launch_pv_build(c->d_images, c->d_stream_image, c->d_pv_rows, (uint32_t)rows.size(), c->d_vals, c->n_streams, c->hs));
+        }
+    }
     return 0;
 }
 
@@ -369,7 +457,7 @@ void dspi_destroy(dspi_ctx *c) {
     if (c->device != DSPI_DEVICE_NONE) {
         (void)hipSetDevice(c->device);
         if (c->hs) (void)hipStreamSynchronize(c->hs);
-        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_xwords, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_stream_image, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
+        for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_xwords, (void *)c->d_vals, (void *)c->d_pv_rows, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_stream_image, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
             if (p) (void)hipFree(p);
         if (c->hs) (void)hipStreamDestroy(c->hs);
@@ -651,10 +739,11 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     // per-lane-parameter kernel for both lane components in one launch (list 2).  Q28: rows with one image run workgroup-uniform
     // (list 0), rows with several in per-lane-parameter mode (list 2).  A launch covers every image.
     struct Launch { int list; int packed; };
-    static const Launch kF32[] = {{1, 1}, {2, 2}};
+    static const Launch kF32[] = {{1, 1}, {3, 3}, {2, 2}};      // list 3: per-lane-value rows (packed kernel + value tiles)
     static const Launch kQ28[] = {{0, 0}, {2, 2}};
     const Launch *ls = c->flavor ? kF32 : kQ28;
-    const int nl = 2;
+    const int nl = c->flavor ? 3 : 2;
+    a.vals = c->d_vals;
     for (int lev = 0; lev < 2; lev++)
         for (int l = 0; l < nl; l++) {
             const auto &items = c->launch_items[lev][ls[l].list];

@@ -72,6 +72,26 @@ struct DevImage {
 };
 
 // ------------------------------------------------------------------------------------------
+// Value tile of a row (packed float kernel, per-lane values): what DIFFERS between the presets of a row whose 128 streams
+// share one structure (flags, band kinds, bypasses, enables, delays in samples, zero pattern of the crosspoints) but not
+// their numbers.  Lane l holds streams 2l (a) and 2l+1 (b) of the row; every access below is one coalesced row per wave.
+//   bands    float4 [kPvBandSlots][3][64 lanes] = {c[2j].a, c[2j].b, c[2j+1].a, c[2j+1].b}   slot = ch*kBands + band, then loud[0..1]
+//   scalars  float2 [PV_COUNT][64 lanes]        = {value of a, value of b}
+// ------------------------------------------------------------------------------------------
+constexpr int kPvBandSlots = kMaxCh * kBands + 2;
+enum PvScalar : int {
+    PV_PREAMP0 = 0, PV_PREAMP1, PV_VOL, PV_MASTER,
+    PV_MIX0,                              // + o
+    PV_MIX1 = PV_MIX0 + kMaxOut,          // + o
+    PV_OG = PV_MIX1 + kMaxOut,            // + o : out_gain_lin
+    PV_LV = PV_OG + kMaxOut,              // alpha_rms attack release threshold ratio knee makeup gate max_gain
+    PV_XF = PV_LV + 9,                    // lp_a0 lp_b1 ap_a
+    PV_COUNT = PV_XF + 3,
+};
+constexpr int kPvBandFloats = kPvBandSlots * 3 * kLanes * 4;            // 86 016
+constexpr int kPvTileFloats = kPvBandFloats + PV_COUNT * kLanes * 2;    // 91 648 floats = 366 592 bytes per row
+
+// ------------------------------------------------------------------------------------------
 // Per-stream state: [workgroup][slot][lane] 32-bit words.  Slots 0..lds_slots-1 are staged in
 // LDS for the whole launch; the rest live in VGPRs of the wave that owns them.
 // ------------------------------------------------------------------------------------------

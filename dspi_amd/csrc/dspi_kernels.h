@@ -23,6 +23,7 @@ struct KArgs {
     const uint32_t *stream_image;   // [n_streams] image index of every stream (float one-stream kernel: per-lane parameters)
     uint32_t tiled_out;      // DSPI_OUT_TILED: pairs = [tile][output][frames][row], sub = [tile][frames][row] (row = StateMap::row)
     uint32_t *xwords;        // packed float kernel, stream-major output: exchange area [n_wg][2][kMaxOut][kChunk][128] words (or null: scattered stores)
+    const float *vals;       // packed float kernel, per-lane values: value tiles [n_wg][kPvTileFloats] (dspi_image.h) or null
     uint32_t fma;            // float flavour: the context's contract is DSPI_FLOAT_CONTRACT_FMA (selects the kernel family at launch)
 };
 
@@ -30,10 +31,14 @@ size_t chain_lds_bytes(int flavor, int packed);
 // packed: 1 = packed float kernel (items list lanes whose two streams share the item's image); 0 = one stream per lane
 // with the item's image for the whole workgroup (Q28); 2 = one stream per lane, every lane its own image
 // (args.stream_image; float: stream WgItem::image (0 / 1) of each listed lane; Q28: rows with several presets)
+// packed 3 = packed float kernel with per-lane VALUES: one item per row whose streams share a structure, WgItem::image = any
+// image of the row (read for the structure only), numbers from args.vals
 // leveller_on: IF_LEVELLER_ON of every image in args.items (the host groups them; the packed kernel is specialised on it)
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
                             uint32_t *ring, uint32_t n_streams, hipStream_t stream);
+// (re)build the value tiles of the listed rows from the images of their streams
+hipError_t launch_pv_build(const DevImage *img, const uint32_t *stream_image, const uint32_t *rows, uint32_t n_rows, float *vals, uint32_t n_streams, hipStream_t stream);
 hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream);
 // debug: taps [kBands+1][n] after every band of EQ channel `ch` of *img (float flavour), other [kBands][n] = the other
 // contract's one-step result from the same input and state

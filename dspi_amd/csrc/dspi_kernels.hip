@@ -1470,33 +1470,74 @@ static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_
     return hipGetLastError();
 }
 
-template <bool TAIL, bool LEV, bool PCM24, bool TILED, bool FMA>
+template <bool TAIL, bool LEV, bool PCM24, bool TILED, bool FMA, bool PV>
 static hipError_t launch_chain_pk_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(1, 1);
     static bool attr_set[kMaxDevices] = {};      // per device, see launch_chain_t
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
     if (!attr_set[dev] || dev == kMaxDevices - 1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA, PV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
+    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA, PV>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
     return hipGetLastError();
 }
 
-template <bool TAIL, bool LEV, bool FMA>
+template <bool TAIL, bool LEV, bool FMA, bool PV>
 static hipError_t launch_chain_pk_2(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const bool p24 = args.bit_depth == 24, tl = args.tiled_out != 0;
-    if (p24) return tl ? launch_chain_pk_t<TAIL, LEV, true, true, FMA>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, true, false, FMA>(args, n_items, stream);
-    return tl ? launch_chain_pk_t<TAIL, LEV, false, true, FMA>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, false, false, FMA>(args, n_items, stream);
+    if (p24) return tl ? launch_chain_pk_t<TAIL, LEV, true, true, FMA, PV>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, true, false, FMA, PV>(args, n_items, stream);
+    return tl ? launch_chain_pk_t<TAIL, LEV, false, true, FMA, PV>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, false, false, FMA, PV>(args, n_items, stream);
 }
 
-template <bool FMA>
+template <bool FMA, bool PV>
 static hipError_t launch_chain_pk(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream) {
     const bool tail = (args.block_len % T) != 0;
-    if (tail) return leveller_on ? launch_chain_pk_2<true, true, FMA>(args, n_items, stream) : launch_chain_pk_2<true, false, FMA>(args, n_items, stream);
-    return leveller_on ? launch_chain_pk_2<false, true, FMA>(args, n_items, stream) : launch_chain_pk_2<false, false, FMA>(args, n_items, stream);
+    if (tail) return leveller_on ? launch_chain_pk_2<true, true, FMA, PV>(args, n_items, stream) : launch_chain_pk_2<true, false, FMA, PV>(args, n_items, stream);
+    return leveller_on ? launch_chain_pk_2<false, true, FMA, PV>(args, n_items, stream) : launch_chain_pk_2<false, false, FMA, PV>(args, n_items, stream);
+}
+
+// ---- value tiles of the per-lane-value rows (dspi_image.h): one thread per (row, word, column) ----
+__global__ __launch_bounds__(256) void pv_build_kernel(const DevImage *img, const uint32_t *stream_image, const uint32_t *rows, float *vals, uint32_t n_streams) {
+    constexpr int kWords = kPvBandSlots * 6 + PV_COUNT;
+    const uint32_t wg = rows[blockIdx.y];
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;             // word * 128 + column: a wave writes columns of one word
+    const uint32_t w = idx >> 7, col = idx & 127u;
+    if (w >= (uint32_t)kWords) return;
+    const uint32_t stream = wg * 128u + col;
+    float *tile = vals + (size_t)wg * kPvTileFloats;
+    float v = 0.0f;
+    const DevImage *im = stream < n_streams ? img + stream_image[stream] : nullptr;
+    size_t dst;
+    if (w < (uint32_t)kPvBandSlots * 6u) {
+        const uint32_t slot = w / 6u, k = w % 6u;
+        if (im) v = (slot < (uint32_t)(kMaxCh * kBands)) ? im->eq[slot / kBands][slot % kBands].c[k].f : im->loud[slot - kMaxCh * kBands].c[k].f;
+        dst = ((size_t)(slot * 3u + (k >> 1)) * kLanes + (col >> 1)) * 4u + (k & 1u) * 2u + (col & 1u);
+    } else {
+        const int s = (int)w - kPvBandSlots * 6;
+        if (im) {
+            if (s == PV_PREAMP0) v = im->preamp[0].f;
+            else if (s == PV_PREAMP1) v = im->preamp[1].f;
+            else if (s == PV_VOL) v = im->vol.f;
+            else if (s == PV_MASTER) v = im->master.f;
+            else if (s < PV_MIX1) v = im->mix[0][s - PV_MIX0].f;
+            else if (s < PV_OG) v = im->mix[1][s - PV_MIX1].f;
+            else if (s < PV_LV) v = im->out_gain_lin[s - PV_OG];
+            else if (s < PV_XF) { const float *lv = &im->lv_alpha_rms; v = lv[s - PV_LV]; }      // nine consecutive floats (dspi_image.h)
+            else { const Word *xf = &im->xf_lp_a0; v = xf[s - PV_XF].f; }
+        }
+        dst = (size_t)kPvBandFloats + ((size_t)s * kLanes + (col >> 1)) * 2u + (col & 1u);
+    }
+    tile[dst] = v;
+}
+
+hipError_t launch_pv_build(const DevImage *img, const uint32_t *stream_image, const uint32_t *rows, uint32_t n_rows, float *vals, uint32_t n_streams, hipStream_t stream) {
+    constexpr int kWords = kPvBandSlots * 6 + PV_COUNT;
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(pv_build_kernel, dim3((kWords * 128 + 255) / 256, n_rows), dim3(256), 0, stream, img, stream_image, rows, vals, n_streams);
+    return hipGetLastError();
 }
 
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream) {
@@ -1504,8 +1545,9 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
     // per-lane images (float always; Q28 rows with several presets)
     if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
     // float: the context's contract (DSPI_FLOAT_CONTRACT_FMA) picks the kernel family
-    if (packed != 1) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
-    return args.fma ? launch_chain_pk<true>(args, leveller_on, n_items, stream) : launch_chain_pk<false>(args, leveller_on, n_items, stream);
+    if (packed != 1 && packed != 3) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
+    if (packed == 3) return args.fma ? launch_chain_pk<true, true>(args, leveller_on, n_items, stream) : launch_chain_pk<false, true>(args, leveller_on, n_items, stream);
+    return args.fma ? launch_chain_pk<true, false>(args, leveller_on, n_items, stream) : launch_chain_pk<false, false>(args, leveller_on, n_items, stream);
 }
 
 // ---- debug: per-band taps of one float EQ channel (include/dspi.h dspi_debug_eq_taps) ----

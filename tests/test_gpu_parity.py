@@ -221,6 +221,70 @@ def test_many_presets_one_process_call(flavor):
     d.close()
 
 
+@pytest.mark.parametrize("fma", [False, True])
+@pytest.mark.parametrize("fs,B,depth,S,lev", [(96000, 96, 16, 300, 1), (44100, 45, 24, 131, 1), (48000, 48, 16, 140, 0), (44100, 44, 16, 70, 0)])
+def test_one_structure_different_numbers(fma, fs, B, depth, S, lev):
+    """SURVEY §8f-1, the product-family case: every stream its own preset, all of ONE structure (same filter types, bypasses, routing
+    pattern, delays) with different numbers everywhere a number can differ without changing the structure — every band's gain and Q,
+    preamps, master volume, crosspoint gains, output gains, leveller amount / speed / gate / max gain, custom crossfeed — plus
+    per-stream UAC1 volume and mute.  Such rows run the packed kernel with per-lane values (value tiles, dspi_image.h); the odd
+    last stream of the 131-stream case and a stream of a different structure dropped into row 0 take the one-stream kernel.
+    Numbers change again between the two calls (the tiles are rebuilt); every stream must match its own oracle."""
+    blocks = 6
+    flavor = W.F32_FMA if fma else 1
+    d = Dspi(flavor, S, device=0); o = [Oracle(flavor, detmath=True) for _ in range(S)]
+    blob = WL.full_chain_blob(1)
+    blob["leveller"]["enabled"] = lev
+    for x in [d] + o:
+        x.set_rate(fs); x.set_volume(-9 * 256); assert x.load_bulk(blob) == 0
+    R = W.REQ
+    f = lambda v: struct.pack("<f", v)
+    rng = np.random.default_rng(23 + S)
+    recipes = {}
+
+    def numbers(s_, call):
+        reqs = [(R["SET_PREAMP_CH"], 0, f(-15.0 + 0.02 * s_)), (R["SET_PREAMP_CH"], 1, f(-14.0 - 0.01 * s_)), (R["SET_MASTER_VOLUME"], 0, f(-0.05 * (s_ % 60) - call))]
+        for _ in range(6):        # same type and frequency (the kind depends on both), new gain and Q
+            ch, band = int(rng.integers(0, 11)), int(rng.integers(0, 10))
+            p = blob["eq"][ch][band]
+            if int(p["type"]) == W.FILTER_FLAT: continue
+            reqs.append((R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, band, int(p["type"]), 0, float(p["freq"]), float(rng.uniform(0.5, 3.0)), float(rng.uniform(-9, 9)) or 1.0)))
+        o_ = int(rng.integers(0, 9))
+        reqs.append((R["SET_OUTPUT_GAIN"], o_, f(float(rng.uniform(-12, 3)))))
+        for i_ in range(2):       # a routed crosspoint keeps a non-zero gain (its zero pattern is structure)
+            o2 = int(rng.integers(0, 9))
+            xp = blob["crosspoints"][i_][o2]
+            if int(xp["enabled"]): reqs.append((R["SET_MATRIX_ROUTE"], 0, struct.pack("<BBBBf", i_, o2, 1, int(xp["phase_invert"]), float(rng.uniform(-9, 0)))))
+        reqs += [(R["SET_LEVELLER_AMOUNT"], 0, f(float(rng.uniform(10, 100)))), (R["SET_LEVELLER_SPEED"], 0, bytes([int(rng.integers(0, 3))])),
+                 (R["SET_LEVELLER_MAX_GAIN"], 0, f(float(rng.uniform(3, 20)))), (R["SET_LEVELLER_GATE"], 0, f(float(rng.uniform(-90, -50))))]
+        if int(blob["crossfeed"]["enabled"]):
+            reqs += [(R["SET_CROSSFEED_PRESET"], 0, b"\x03"), (R["SET_CROSSFEED_FREQ"], 0, f(float(rng.uniform(500, 1500)))), (R["SET_CROSSFEED_FEED"], 0, f(float(rng.uniform(3, 12))))]
+        return reqs
+
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
+    data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm)
+    per = B * blocks * (1 if depth == 16 else 6)
+    for call in range(2):
+        for s_ in range(S):
+            if call == 1 and s_ % 3: continue
+            for req, wv, pl in numbers(s_, call):
+                assert d.vendor_set(req, wv, pl, stream=s_) == 0 and o[s_].vendor_set(req, wv, pl) == 0
+            if s_ % 11 == 5:
+                v = -256 * int(rng.integers(0, 40)); d.set_volume(v, stream=s_); o[s_].set_volume(v)
+            if s_ % 37 == 9:
+                d.set_mute(call == 0, stream=s_); o[s_].set_mute(call == 0)
+        if call == 0:             # one stream of another structure in the middle of row 0: its lane leaves the packed kernel
+            for x in (lambda *a: d.vendor_set(*a, stream=17), o[17].vendor_set):
+                assert x(R["SET_OUTPUT_MUTE"], 2, b"\x01") == 0
+        chunk = np.ascontiguousarray(data[:, call * per:(call + 1) * per])
+        pairs, sub, peaks = d.process_host(chunk, blocks, B, depth)
+        for s_ in range(S):
+            rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B, depth)
+            assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (call, s_)
+            assert o[s_].status() == d.status(s_)
+    d.close()
+
+
 @pytest.mark.parametrize("flavor,fs,B,depth,S", [(1, 48000, 48, 16, 200), (1, 44100, 45, 24, 70), (0, 48000, 48, 16, 150), (0, 44100, 44, 24, 70)])
 def test_every_stream_its_own_preset(flavor, fs, B, depth, S):
     """every stream (both flavours) carries a different preset — different band kinds at the same band index (SVF

@@ -19,6 +19,10 @@ def run(label, blob, outputs=True, steps=4):
     d = Dspi(1, S, device=0, fma=bool(os.environ.get('FMA')))
     d.set_rate(FS); d.set_volume(-20 * 256)
     assert d.load_bulk(blob) == 0
+    if os.environ.get('PERSTREAM'):      # every stream its own preset of one structure: the packed kernel with per-lane values
+        import struct
+        for s_ in range(S):
+            d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s_), stream=s_)
     args = (pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr()) if outputs else (0, 0, 0)
     d.process_device(pcm.data_ptr(), NB, B, 16, *args, tiled=TILED); d.sync()
     t0 = time.perf_counter()

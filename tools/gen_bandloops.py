@@ -22,6 +22,7 @@ import os
 
 T = 16
 FMA = False     # which float contract the lists below describe; main() emits both (see ops())
+VCOEF = False   # packed family with PER-LANE coefficients: six VGPR pairs c0..c5 (one value per stream of the lane), no op_sel
 
 # ---------------------------------------------------------------------------------------------------------
 # operation lists: (op, dst, a, b) with op in mul/add/sub/mov; operands: 'x' (sample, in place), 's1','s2',
@@ -142,6 +143,8 @@ def pk_operand(n, i):
     if n[0] == 't':
         return '%%[t%d_%s]' % (i % NTSETS, n[1]), ''
     c = int(n[1])
+    if VCOEF:
+        return '%%[c%d]' % c, ''
     return '%%[c%d%d]' % (c & ~1, c | 1), ('lo' if c % 2 == 0 else 'hi')
 
 
@@ -451,6 +454,34 @@ def emit_n(name, kinds, out):
     out.append("")
 
 
+def emit_v(name, kinds, out, with_n):
+    """Packed, per-lane coefficients (rows whose streams carry different presets of one structure): the band kind is still
+    wave-uniform (scalar dispatch), the six coefficients are VGPR pairs {stream a, stream b} loaded from the row's value tile."""
+    lines = []
+    if with_n:
+        lines += ["s_cmp_lg_u32 %[n], 16", "s_cbranch_scc1 .Ltail_%="]
+    lines += dispatch(kinds, block_pk, 'k', 'f', '.Lend_%=')
+    if with_n:
+        lines += [".Ltail_%=:"]
+        lines += dispatch(kinds, lambda kind: tail_block(kind, pk_line), 'k', 't', '.Lend_%=')
+    lines += [".Lend_%=:"]
+    body = '\n'.join('        "%s\\n\\t"' % l for l in lines)
+    xs = ', '.join('[x%d] "+v"(x[%d])' % (i, i) for i in range(T))
+    tn = ['t%d_%d' % (s_, j) for s_ in range(NTSETS) for j in range(4)]
+    ts = ', '.join('[%s] "=&v"(%s)' % (t, t) for t in tn)
+    out.append("__device__ __forceinline__ void %s(v2f (&x)[16], v2f &s1, v2f &s2, uint32_t kind, v2f c0, v2f c1, v2f c2, v2f c3, v2f c4, v2f c5%s) {"
+               % (name, ", uint32_t n" if with_n else ""))
+    out.append("    v2f %s;" % ', '.join(tn))
+    out.append("    const v2f two = {2.0f, 2.0f};")
+    out.append("    asm volatile(")
+    out.append(body)
+    out.append("        : %s, [s1] \"+v\"(s1), [s2] \"+v\"(s2), %s" % (xs, ts))
+    out.append("        : [k] \"s\"(kind), %s, [two] \"s\"(two)%s" % (', '.join('[c%d] \"v\"(c%d)' % (i, i) for i in range(6)), ', [n] \"s\"(n)' if with_n else ''))
+    out.append("        : \"scc\");")
+    out.append("}")
+    out.append("")
+
+
 HEADER = ["// %s — GENERATED by tools/gen_bandloops.py; do not edit by hand.",
           "// Hand-scheduled gfx950 band loops: 16 samples of one EQ band, in place on tied VGPRs (\"+v\"), coefficients in SGPRs.",
           "// One multiply/add/subtract per reference operation, in the reference's association order (dsp_pipeline.c:298-362).",
@@ -458,7 +489,7 @@ HEADER = ["// %s — GENERATED by tools/gen_bandloops.py; do not edit by hand.",
 
 
 def main():
-    global FMA
+    global FMA, VCOEF, NTSETS
     allk = [('BQ', 1), ('LP', 2), ('HP', 3), ('PK', 4), ('SH', 5)]
     here = os.environ.get('BL_OUT') or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dspi_amd", "csrc")
     for fma in (False, True):
@@ -487,6 +518,22 @@ def main():
             path = os.path.join(here, fname)
             open(path, "w").write('\n'.join(out))
             print("wrote", os.path.normpath(path))
+        # packed, per-lane coefficients: two rotating temp sets (that kernel runs at the memory system's pace and has no registers
+        # to spare: its coefficients are twelve VGPRs per band in flight)
+        VCOEF = True
+        ntsets_pk, NTSETS = NTSETS, int(os.environ.get('BL_NTSETS_V', 2))
+        fname = "dspi_bandloops_pkv%s.inc" % tag
+        out = [HEADER[0] % fname] + HEADER[1:] + ["// two streams per lane, PER-LANE coefficients (six VGPR pairs), wave-uniform kind; list-scheduled; needs v2f"]
+        if fma:
+            out += ["// FLOAT CONTRACT OF THE FIRMWARE BUILD (DSPI_FLOAT_CONTRACT_FMA), see ops() in the generator."]
+        out += [""]
+        emit_v("band16pkv%s_any" % f, allk, out, False)
+        emit_v("band16pkv%s_any_n" % f, allk, out, True)
+        VCOEF = False
+        NTSETS = ntsets_pk
+        path = os.path.join(here, fname)
+        open(path, "w").write('\n'.join(out))
+        print("wrote", os.path.normpath(path))
 
 
 if __name__ == "__main__":
