@@ -1188,7 +1188,24 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
 
     int32_t *q_mail = reinterpret_cast<int32_t *>(xch) + 2 * 2 * T * kLanes;      // [kQ28Mail][64] queued gain decisions (role 0)
     int32_t *q_envr = q_mail + kQ28Mail * kLanes;                                 // [2][64] right envelope at packet end (role 3 -> role 0)
-    if (wave == 0 && FLAVOR == 0) {
+    // Q28 roles: 0 = left pass 1 + hand-off (the lightest, ~16 band-visit equivalents per chunk), 1 / 2 = two outputs each (22),
+    // 3 = right pass 1 + the fifth output (24).  Two workgroups share a CU; the four waves of a workgroup always land on four
+    // different SIMDs (in no fixed order) and all of them in the same wave slot, slot 0 for the first workgroup of the CU and
+    // slot 1 for the second (tools/probe/probe7).  So the role is taken from the SIMD id, in reverse order in the odd slot: every
+    // SIMD then carries roles r and 3 - r (40 / 44 / 44 / 40) instead of the same role twice (32 / 44 / 44 / 48).  Any
+    // assignment is correct; should the placement ever not give four different roles, the wave index is used.
+    int role = wave;
+    if (FLAVOR == 0) {
+        uint32_t *role_tab = reinterpret_cast<uint32_t *>(q_envr + 2 * kLanes);     // [4]
+        const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (5 << 11));      // hwreg(HW_REG_HW_ID, 0, 6): wave slot [3:0], SIMD [5:4]
+        const uint32_t simd = (hw >> 4) & 3u;
+        const uint32_t mine = (hw & 1u) ? 3u - simd : simd;
+        if (lane == (uint32_t)__builtin_ctzll(item.mask)) role_tab[wave] = mine;
+        __syncthreads();
+        const uint32_t seen = (1u << role_tab[0]) | (1u << role_tab[1]) | (1u << role_tab[2]) | (1u << role_tab[3]);
+        role = __builtin_amdgcn_readfirstlane(seen == 15u ? (int)mine : wave);
+    }
+    if (role == 0 && FLAVOR == 0) {
         // ---- role 0: pass 1 of the left channel + hand-off of both ----
         int32_t *qstate = reinterpret_cast<int32_t *>(lds);
         int32_t *qxch = reinterpret_cast<int32_t *>(xch);
@@ -1257,14 +1274,14 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         int32_t *qpk = reinterpret_cast<int32_t *>(lds_pk);
         const int32_t *qxch = reinterpret_cast<const int32_t *>(xch);
         // 5 outputs over waves 1..3: pair 0, pair 1, sub; wave 3 also runs pass 1 of the right channel (role 3 above)
-        const int o_first = (wave - 1) * 2;
-        const int o_count = (wave <= sm.n_pairs) ? 2 : 1;
-        const bool right = (wave == 3);
+        const int o_first = (role - 1) * 2;
+        const int o_count = (role <= sm.n_pairs) ? 2 : 1;
+        const bool right = (role == 3);
         OutQ28 s;
         s.widx = gs[sm.widx * ROW];
         s.loading = gs[(sm.mute + 0) * ROW]; s.counter = gs[(sm.mute + 1) * ROW]; s.smooth = as_f(gs[(sm.mute + 2) * ROW]);
         s.vmm = 0;
-        s.clip = gs[(sm.clip + wave) * ROW];
+        s.clip = gs[(sm.clip + role) * ROW];
         int32_t env_r = right ? (int32_t)gs[(sm.lev + 1) * ROW] : 0;
         uint32_t rp1 = gs[sm.ring_pos * ROW] & (kRingLen - 1);
         uint32_t kq = 0, cq = 0, k1 = 0, c1 = 0;
@@ -1292,12 +1309,12 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             }
             lds_barrier();
         }
-        if (wave == 1) {
+        if (role == 1) {
             gs[sm.widx * ROW] = s.widx;
             gs[(sm.mute + 0) * ROW] = s.loading; gs[(sm.mute + 1) * ROW] = s.counter; gs[(sm.mute + 2) * ROW] = as_u(s.smooth);
         }
         if (right) gs[(sm.lev + 1) * ROW] = (uint32_t)env_r;
-        gs[(sm.clip + wave) * ROW] = s.clip;
+        gs[(sm.clip + role) * ROW] = s.clip;
     } else if (wave == 0) {
         MasterF32 m;
         m.lpL = as_f(gs[(sm.xfeed + 0) * ROW]); m.lpR = as_f(gs[(sm.xfeed + 1) * ROW]);
@@ -1445,8 +1462,8 @@ __global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
 // ------------------------------------------------------------------------------------------
 size_t chain_lds_bytes(int flavor, int packed) {
     const StateMap sm = make_state_map(flavor);
-    // Q28 one-stream kernel: + queued gain decisions and the posted right-channel envelope (kQ28Mail + 2 rows)
-    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox : (flavor ? 0 : 6))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);
+    // Q28 one-stream kernel: + queued gain decisions, the posted right-channel envelope and the role table (kQ28Mail + 2 + 1 rows)
+    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox : (flavor ? 0 : 7))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);
 }
 
 constexpr int kMaxDevices = 65;      // slot 64: any device index beyond (attribute set on every launch)
