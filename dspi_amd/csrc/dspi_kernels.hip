@@ -1295,6 +1295,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
                     else master_p1_q28<false, 1>(a, img, sm, g, env_r, rp1, qstate, wg, lane, stream, k1, c1);
                 }
                 if (++c1 == g.cpb) { q_envr[(k1 & 1u) * kLanes + lane] = env_r; c1 = 0; ++k1; }
+            } else if (right) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last chunks' ring rows (master_p1_q28 drains one step late)
             }
             if (st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;

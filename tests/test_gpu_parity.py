@@ -414,6 +414,7 @@ def test_full_size_all_tiles_agree(flavor, fs, B):
     for c in range(calls):
         part = torch.from_numpy(np.ascontiguousarray(base[:, c * frames:(c + 1) * frames])).to(dev)
         pcm = part.repeat(tiles, 1, 1).contiguous()
+        torch.cuda.synchronize()        # the context launches on its own stream: the input must be complete before it starts
         d.process_device(pcm.data_ptr(), blocks, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=True); d.sync()
         assert bool((pairs == pairs[0:1]).all()), f"launch {c}: a tile's pair words differ from tile 0"
         assert bool((sub == sub[0:1]).all()), f"launch {c}: a tile's sub words differ from tile 0"
