@@ -9,7 +9,7 @@ packets, the full RP2350 11-channel chain (preamp, loudness, 10-band master PEQ,
     python bench.py                         1 GPU, config 3
     python bench.py --gpus N                N ranks on one node: spawned here (torchrun) when not already under a launcher
     python bench.py --scaling strong        65 536 streams in total, split over the ranks (dspi_amd/shard.py)
-    python bench.py --config {2,2b,5,perstream,pdm,spdif,i2s}     the other BASELINE configs / SURVEY section 8f consumers, same JSON shape
+    python bench.py --config {2,2b,5,perstream,perstream_eq,pdm,spdif,i2s}     the other BASELINE configs / SURVEY section 8f consumers, same JSON shape
 
 Multi-GPU: one process per GPU, streams sharded per rank, no data-path collective; RCCL only for the barrier and the
 max-over-ranks time.  DSPI_BENCH_BACKEND=gloo lets the ranks share GPUs (control-flow smoke test on a 1-GPU box).
@@ -184,8 +184,12 @@ def chain_workload(name):
                     text="BASELINE config 5: RP2040 Q28 fixed-point 7-channel chain (5 outputs, delays <= 40 ms), 16 384 streams, 48 kHz, 48-frame packets")
     if name == "perstream":
         return dict(flavor=1, fs=96000, B=96, streams=65536, blocks=50, channels=11, vol=-20 * 256, blob=WL.full_chain_blob(1), perstream=True,
-                    text="SURVEY 8f-1: config 3 with 65 536 DISTINCT presets of one structure (one parameter image per stream; packed kernel with per-lane "
-                         "values read from value tiles)")
+                    text="SURVEY 8f-1: config 3 with 65 536 DISTINCT presets of one structure and identical filters (preamp per stream; one parameter image "
+                         "per stream; packed kernel, gains / volumes / leveller numbers per lane from value tiles, band coefficients shared)")
+    if name == "perstream_eq":
+        return dict(flavor=1, fs=96000, B=96, streams=65536, blocks=50, channels=11, vol=-20 * 256, blob=WL.full_chain_blob(1), perstream="eq",
+                    text="SURVEY 8f-1: config 3 with 65 536 DISTINCT presets of one structure whose FILTERS differ too (a master band's gain per stream: "
+                         "every band coefficient is then read per lane from the value tiles, 180 B/frame of extra traffic)")
     raise SystemExit(f"unknown config {name}")
 
 
@@ -236,7 +240,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="3", choices=["3", "2", "2b", "5", "perstream", "pdm", "spdif", "i2s"])
+    ap.add_argument("--config", default="3", choices=["3", "2", "2b", "5", "perstream", "perstream_eq", "pdm", "spdif", "i2s"])
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (weak) or in total (strong); 0 = the config's own")
     ap.add_argument("--blocks-per-step", type=int, default=0, help="packets per dspi_process call; 0 = the config's own")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -339,6 +343,9 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
             import struct
             for s in range(S):
                 ctx.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s), stream=s)
+                if w["perstream"] == "eq":
+                    p = w["blob"]["eq"][0][0]
+                    ctx.vendor_set(W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", 0, 0, int(p["type"]), 0, float(p["freq"]), float(p["q"]), 1.0 + 0.0001 * s), stream=s)
         if inp not in pcm_cache:
             pcm_cache.clear()
             pcm_cache[inp] = synth_device(torch, dev, S, frames, FS, 1234 + rank, inp == "mix", first)
@@ -375,7 +382,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         return None
 
     full_b, span_b = algorithmic_bytes(w, frames)
-    kernel_key = {"3": "chain3", "2": "chain2", "2b": "chain2b", "5": "chain5", "perstream": "perstream"}[args.config]
+    kernel_key = {"3": "chain3", "2": "chain2", "2b": "chain2b", "5": "chain5", "perstream": "perstream", "perstream_eq": "perstream_eq"}[args.config]
 
     def roof(m):
         per_launch_frames = S * frames
@@ -392,8 +399,8 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         return r
 
     if flavor == 1:
-        kname = "chain_kernel_pk<false, true, false, %s, %s, %s>" % ("true" if args.out_layout == "tiled" else "false", "true" if args.contract == "fma" else "false",
-                                                                     "true" if w.get("perstream") else "false")
+        kname = "chain_kernel_pk<false, true, false, %s, %s, %s, %s>" % ("true" if args.out_layout == "tiled" else "false", "true" if args.contract == "fma" else "false",
+                                                                         "true" if w.get("perstream") else "false", "true" if w.get("perstream") == "eq" else "false")
         if CH == 2: kname = kname.replace("<false, true", "<false, false")
     else:
         kname = "chain_kernel<0, false, false, false>"

@@ -40,8 +40,8 @@ struct dspi_ctx {
     std::vector<uint32_t> image_item_offset[4];
     // chain launches: the same work lists concatenated over images, grouped by what the kernels are specialised on
     // (float: leveller on/off), so a dspi_process is a handful of launches however many presets are in play
-    std::vector<WgItem> launch_items[2][4];
-    uint32_t launch_item_offset[2][4] = {};
+    std::vector<WgItem> launch_items[2][5];
+    uint32_t launch_item_offset[2][5] = {};
     WgItem *d_litems = nullptr; size_t d_litems_cap = 0;
     uint32_t *d_stream_image = nullptr; size_t d_stream_image_cap = 0;   // image index per stream (per-lane parameter kernel)
     bool launch_dirty = true;
@@ -58,6 +58,9 @@ struct dspi_ctx {
         int32_t delay[kMaxOut];
         uint8_t kinds[kPvBandSlots];
     };
+    struct BandHash { uint64_t a, b; };            // two independent 64-bit hashes of an image's band coefficient words: rows whose
+    std::vector<BandHash> image_bands;             // images agree in both run the shared band loops (row_pv = 2), the rest of the
+                                                   // numbers per lane
     std::vector<ImageSig> image_sig;
     std::vector<uint8_t> row_pv;                   // [n_wg] the row is a per-lane-value row
     std::vector<uint8_t> image_touched;            // images uploaded since the tiles were last built
@@ -195,6 +198,14 @@ dspi_ctx::ImageSig make_sig(const DevImage &img) {
     return g;
 }
 
+dspi_ctx::BandHash hash_bands(const DevImage &img) {
+    uint64_t a = 0xcbf29ce484222325ull, b = 0x9e3779b97f4a7c15ull;      // FNV-1a and a multiply-xorshift mix over the same words
+    auto feed = [&](uint32_t w) { a = (a ^ w) * 0x100000001b3ull; b = (b + w) * 0xff51afd7ed558ccdull; b ^= b >> 29; };
+    for (int ch = 0; ch < kMaxCh; ch++) for (int k = 0; k < kBands; k++) for (int j = 0; j < 6; j++) feed(img.eq[ch][k].c[j].u);
+    for (int k = 0; k < 2; k++) for (int j = 0; j < 6; j++) feed(img.loud[k].c[j].u);
+    return dspi_ctx::BandHash{a, b};
+}
+
 int rebuild_launch_lists(dspi_ctx *c) {
     // lists 0 (Q28) and 1 (float lanes whose two streams share an image): one item per (row, image), grouped by leveller
     // on/off for the float kernel variants.  List 2 (float lanes with ONE stream of an image — image_items 2 / 3 = first /
@@ -202,7 +213,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
     // lane's own image, so all images of a row merge into one item.  Launch list 3 stays empty.
     size_t total = 0;
     // float: rows holding several images of ONE structure -> per-lane-value rows (launch list 3, packed kernel + value tile)
-    struct RowAcc { uint64_t m0 = 0, m1 = 0; int n = 0; uint32_t first = 0; bool same = true; };
+    struct RowAcc { uint64_t m0 = 0, m1 = 0; int n = 0; uint32_t first = 0; bool same = true, same_bands = true; };
     std::map<uint32_t, RowAcc> rows_f;
     c->row_pv.assign(c->n_wg, 0);
     if (c->flavor && c->image_sig.size() >= c->images.size()) {
@@ -210,18 +221,22 @@ int rebuild_launch_lists(dspi_ctx *c) {
             for (const WgItem &it : c->image_items[0][i]) {
                 RowAcc &r = rows_f[it.wg];
                 if (r.n++ == 0) r.first = (uint32_t)i;
-                else if (memcmp(&c->image_sig[r.first], &c->image_sig[i], sizeof(dspi_ctx::ImageSig)) != 0) r.same = false;
+                else {
+                    if (memcmp(&c->image_sig[r.first], &c->image_sig[i], sizeof(dspi_ctx::ImageSig)) != 0) r.same = false;
+                    if (c->image_bands[r.first].a != c->image_bands[i].a || c->image_bands[r.first].b != c->image_bands[i].b) r.same_bands = false;
+                }
                 r.m0 |= it.mask; r.m1 |= it.mask1;
             }
-        for (const auto &r : rows_f) if (r.second.n > 1 && r.second.same && (r.second.m0 & r.second.m1)) c->row_pv[r.first] = 1;
+        for (const auto &r : rows_f)
+            if (r.second.n > 1 && r.second.same && (r.second.m0 & r.second.m1)) c->row_pv[r.first] = r.second.same_bands ? 2 : 1;
     }
     for (int lev = 0; lev < 2; lev++)
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             auto &v = c->launch_items[lev][k];
             v.clear();
-            if (k == 3) {
+            if (k >= 3) {      // list 3: per-lane values incl. band coefficients; list 4: identical filters, the other numbers per lane
                 for (const auto &r : rows_f) {
-                    if (!c->row_pv[r.first]) continue;
+                    if (c->row_pv[r.first] != (k == 3 ? 1 : 2)) continue;
                     const int ilev = (c->image_flags[r.second.first] & IF_LEVELLER_ON) ? 1 : 0;
                     if (ilev == lev) v.push_back(WgItem{r.first, r.second.first, r.second.m0 & r.second.m1, 0ull});
                 }
@@ -274,7 +289,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
     if ((rc = ensure(c, c->d_stream_image, c->d_stream_image_cap, (size_t)c->n_streams * 4))) return rc;
     HIPCK(c, hipStreamSynchronize(c->hs));      // no launch may still be reading the lists we overwrite
     for (int lev = 0; lev < 2; lev++)
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 5; k++)
             if (!c->launch_items[lev][k].empty())
                 HIPCK(c, hipMemcpy(c->d_litems + c->launch_item_offset[lev][k], c->launch_items[lev][k].data(),
                                    c->launch_items[lev][k].size() * sizeof(WgItem), hipMemcpyHostToDevice));
@@ -310,7 +325,7 @@ int commit_params(dspi_ctx *c) {
     if (c->image_flags.size() < ni) c->image_flags.resize(ni, 0u);
     if (c->flavor && c->image_sig.size() < ni) {
         dspi_ctx::ImageSig none; memset(&none, 0xff, sizeof none);
-        c->image_sig.resize(ni, none); c->image_touched.resize(ni, 1); c->launch_dirty = true;
+        c->image_sig.resize(ni, none); c->image_bands.resize(ni, dspi_ctx::BandHash{0, 0}); c->image_touched.resize(ni, 1); c->launch_dirty = true;
     }
     std::vector<DevImage> run;
     size_t run0 = 0;
@@ -330,6 +345,8 @@ int commit_params(dspi_ctx *c) {
         if (c->flavor) {
             const dspi_ctx::ImageSig sig = make_sig(run.back());
             if (memcmp(&sig, &c->image_sig[i], sizeof sig) != 0) { c->image_sig[i] = sig; c->launch_dirty = true; }
+            const dspi_ctx::BandHash bh = hash_bands(run.back());
+            if (bh.a != c->image_bands[i].a || bh.b != c->image_bands[i].b) { c->image_bands[i] = bh; c->launch_dirty = true; }
             c->image_touched[i] = 1;
         }
         p.dirty = false;
@@ -739,10 +756,10 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     // per-lane-parameter kernel for both lane components in one launch (list 2).  Q28: rows with one image run workgroup-uniform
     // (list 0), rows with several in per-lane-parameter mode (list 2).  A launch covers every image.
     struct Launch { int list; int packed; };
-    static const Launch kF32[] = {{1, 1}, {3, 3}, {2, 2}};      // list 3: per-lane-value rows (packed kernel + value tiles)
+    static const Launch kF32[] = {{1, 1}, {3, 3}, {4, 4}, {2, 2}};      // lists 3 / 4: per-lane-value rows (packed kernel + value tiles)
     static const Launch kQ28[] = {{0, 0}, {2, 2}};
     const Launch *ls = c->flavor ? kF32 : kQ28;
-    const int nl = c->flavor ? 3 : 2;
+    const int nl = c->flavor ? 4 : 2;
     a.vals = c->d_vals;
     for (int lev = 0; lev < 2; lev++)
         for (int l = 0; l < nl; l++) {

@@ -32,7 +32,8 @@ size_t chain_lds_bytes(int flavor, int packed);
 // with the item's image for the whole workgroup (Q28); 2 = one stream per lane, every lane its own image
 // (args.stream_image; float: stream WgItem::image (0 / 1) of each listed lane; Q28: rows with several presets)
 // packed 3 = packed float kernel with per-lane VALUES: one item per row whose streams share a structure, WgItem::image = any
-// image of the row (read for the structure only), numbers from args.vals
+// image of the row (read for the structure only), numbers from args.vals; packed 4 = the same for rows whose presets have identical
+// FILTERS (band coefficients from the image's scalars, everything else from args.vals)
 // leveller_on: IF_LEVELLER_ON of every image in args.items (the host groups them; the packed kernel is specialised on it)
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,

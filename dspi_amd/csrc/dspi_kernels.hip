@@ -1489,33 +1489,33 @@ static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_
     return hipGetLastError();
 }
 
-template <bool TAIL, bool LEV, bool PCM24, bool TILED, bool FMA, bool PV>
+template <bool TAIL, bool LEV, bool PCM24, bool TILED, bool FMA, bool PV, bool PVB>
 static hipError_t launch_chain_pk_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(1, 1);
     static bool attr_set[kMaxDevices] = {};      // per device, see launch_chain_t
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
     if (!attr_set[dev] || dev == kMaxDevices - 1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA, PV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA, PV, PVB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA, PV>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
+    hipLaunchKernelGGL((chain_kernel_pk<TAIL, LEV, PCM24, TILED, FMA, PV, PVB>), dim3(n_items), dim3(64 * kPkWaves), lds, stream, args);
     return hipGetLastError();
 }
 
-template <bool TAIL, bool LEV, bool FMA, bool PV>
+template <bool TAIL, bool LEV, bool FMA, bool PV, bool PVB>
 static hipError_t launch_chain_pk_2(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const bool p24 = args.bit_depth == 24, tl = args.tiled_out != 0;
-    if (p24) return tl ? launch_chain_pk_t<TAIL, LEV, true, true, FMA, PV>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, true, false, FMA, PV>(args, n_items, stream);
-    return tl ? launch_chain_pk_t<TAIL, LEV, false, true, FMA, PV>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, false, false, FMA, PV>(args, n_items, stream);
+    if (p24) return tl ? launch_chain_pk_t<TAIL, LEV, true, true, FMA, PV, PVB>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, true, false, FMA, PV, PVB>(args, n_items, stream);
+    return tl ? launch_chain_pk_t<TAIL, LEV, false, true, FMA, PV, PVB>(args, n_items, stream) : launch_chain_pk_t<TAIL, LEV, false, false, FMA, PV, PVB>(args, n_items, stream);
 }
 
-template <bool FMA, bool PV>
+template <bool FMA, bool PV, bool PVB>
 static hipError_t launch_chain_pk(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream) {
     const bool tail = (args.block_len % T) != 0;
-    if (tail) return leveller_on ? launch_chain_pk_2<true, true, FMA, PV>(args, n_items, stream) : launch_chain_pk_2<true, false, FMA, PV>(args, n_items, stream);
-    return leveller_on ? launch_chain_pk_2<false, true, FMA, PV>(args, n_items, stream) : launch_chain_pk_2<false, false, FMA, PV>(args, n_items, stream);
+    if (tail) return leveller_on ? launch_chain_pk_2<true, true, FMA, PV, PVB>(args, n_items, stream) : launch_chain_pk_2<true, false, FMA, PV, PVB>(args, n_items, stream);
+    return leveller_on ? launch_chain_pk_2<false, true, FMA, PV, PVB>(args, n_items, stream) : launch_chain_pk_2<false, false, FMA, PV, PVB>(args, n_items, stream);
 }
 
 // ---- value tiles of the per-lane-value rows (dspi_image.h): one thread per (row, word, column) ----
@@ -1564,9 +1564,10 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
     // per-lane images (float always; Q28 rows with several presets)
     if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
     // float: the context's contract (DSPI_FLOAT_CONTRACT_FMA) picks the kernel family
-    if (packed != 1 && packed != 3) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
-    if (packed == 3) return args.fma ? launch_chain_pk<true, true>(args, leveller_on, n_items, stream) : launch_chain_pk<false, true>(args, leveller_on, n_items, stream);
-    return args.fma ? launch_chain_pk<true, false>(args, leveller_on, n_items, stream) : launch_chain_pk<false, false>(args, leveller_on, n_items, stream);
+    if (packed != 1 && packed != 3 && packed != 4) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
+    if (packed == 3) return args.fma ? launch_chain_pk<true, true, true>(args, leveller_on, n_items, stream) : launch_chain_pk<false, true, true>(args, leveller_on, n_items, stream);
+    if (packed == 4) return args.fma ? launch_chain_pk<true, true, false>(args, leveller_on, n_items, stream) : launch_chain_pk<false, true, false>(args, leveller_on, n_items, stream);
+    return args.fma ? launch_chain_pk<true, false, false>(args, leveller_on, n_items, stream) : launch_chain_pk<false, false, false>(args, leveller_on, n_items, stream);
 }
 
 // ---- debug: per-band taps of one float EQ channel (include/dspi.h dspi_debug_eq_taps) ----

@@ -12,7 +12,9 @@ run b "--contract fma --out-layout stream" CONTRACT=fma OUT_LAYOUT=stream KERNEL
 run c "--contract canonical --out-layout tiled" CONTRACT=canonical OUT_LAYOUT=tiled KERNEL_KEY=chain3 NOTE="config 3, canonical contract, tiled words (round-1 configuration)"
 run d "--contract canonical --out-layout stream" CONTRACT=canonical OUT_LAYOUT=stream KERNEL_KEY=chain3 NOTE="config 3, canonical contract, stream-major words"
 run e "--config 5" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=chain5 STREAMS=16384 BLOCK_LEN=48 ALGO_BYTES=56 KERNEL_LIKE="%chain_kernel<0%" NOTE="config 5: Q28 7-channel chain, 16 384 streams, 48 kHz"
-run f "--config perstream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=perstream STREAMS=16384 PACKETS_PER_LAUNCH=25 KERNEL_LIKE="%chain_kernel<1%" NOTE="every stream its own preset: per-lane-parameter float kernel"
+run f "--config perstream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=perstream KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets with identical filters (preamp per stream): packed kernel, per-lane values, shared band coefficients; stream-major words"
+run i "--config perstream_eq --out-layout tiled" CONTRACT=fma OUT_LAYOUT=tiled KERNEL_KEY=perstream_eq KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets whose filters differ: packed kernel, every band coefficient per lane from the value tiles; tiled words"
+run j "--config i2s --out-layout stream" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=i2s PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=64 KERNEL_LIKE="%i2s%" NOTE="I2S slot words, 65 536 streams x 4 pairs x 2 400 frames"
 run g "--config pdm --out-layout tiled" CONTRACT=integer OUT_LAYOUT=tiled KERNEL_KEY=pdm PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=36 KERNEL_LIKE="%pdm_kernel%" NOTE="PDM sigma-delta modulator, 65 536 streams x 2 400 samples (frames = sub samples)"
 run h "--config spdif --out-layout stream" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=spdif PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=96 KERNEL_LIKE="%spdif%" NOTE="S/PDIF subframe encoder, 65 536 streams x 4 pairs x 2 400 frames"
 ls gpurun_out/profsum
