@@ -22,5 +22,5 @@ timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -
 # only returns 64 MiB: summarise on the box, keep the summary (+ traffic json) and drop the databases
 mkdir -p gpurun_out/profsum
 python tools/prof_summary.py $OUT gpurun_out/profsum/${TAG}_summary.md "${NOTE:-}"
-find $OUT -name "*.db" -size +8M -delete
+find $OUT -name "*.db" -delete
 du -sh $OUT
