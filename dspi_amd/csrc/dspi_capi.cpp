@@ -586,6 +586,12 @@ int dspi_debug_image(dspi_ctx *c, int32_t stream, void *buf, size_t cap) {
     return (int)sizeof(img);
 }
 
+int dspi_debug_launch_plan(dspi_ctx *c, uint32_t *counts, size_t n_counts) {
+    if (!c || !counts || n_counts < 5) return DSPI_E_INVAL;
+    for (int k = 0; k < 5; k++) counts[k] = (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size());
+    return 5;
+}
+
 int dspi_debug_eq_taps(dspi_ctx *c, int32_t stream, int channel, const float *x, uint32_t n, float *taps, float *other) {
     if (!c || !x || !taps || !other || n == 0 || n > (1u << 20) || !valid_stream(c, stream) || stream < 0) return DSPI_E_INVAL;
     if (c->flavor != DSPI_FLAVOR_RP2350_F32 || channel < 0 || channel >= c->sm.n_ch) return DSPI_E_INVAL;

@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
     L.dspi_get_status.argtypes = [vp, i32, vp, C.c_size_t]
     L.dspi_clear_clips.argtypes = [vp, i32]
     L.dspi_debug_image.argtypes = [vp, i32, vp, C.c_size_t]
+    L.dspi_debug_launch_plan.argtypes = [vp, vp, C.c_size_t]
     _lib = L
     return L
 
@@ -168,6 +169,12 @@ class Dspi:
         buf = C.create_string_buffer(8192)
         n = self._ck(self.L.dspi_debug_image(self.h, stream, buf, 8192), "debug_image")
         return buf.raw[:n]
+
+    def launch_plan(self) -> dict:
+        """dspi_debug_launch_plan: work items per kernel path after the last process call."""
+        c = (C.c_uint32 * 5)()
+        self._ck(min(self.L.dspi_debug_launch_plan(self.h, c, 5), 0), "debug_launch_plan")
+        return dict(zip(("q28_shared", "packed_shared", "one_stream_per_lane_images", "packed_per_lane_values_and_bands", "packed_per_lane_values"), list(c)))
 
     def eq_taps(self, x: np.ndarray, channel: int, stream: int = 0):
         """dspi_debug_eq_taps: (taps [11][n], other [10][n]) of one EQ channel on the GPU, see include/dspi.h."""

@@ -42,7 +42,8 @@ extern "C" {
 #endif
 
 #define DSPI_ABI_VERSION 4   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
-                              * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1 (additions only) */
+                              * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1,
+                              * dspi_debug_launch_plan (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -209,6 +210,11 @@ int dspi_clear_clips(dspi_ctx *ctx, int32_t stream);
 /* ---- introspection for tests (host-side derived parameter image of a stream) ------------ */
 /* Copies the packed device parameter image; returns its size.  Layout is internal (csrc/dspi_image.h). */
 int dspi_debug_image(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
+/* Which kernel the context's rows currently go to (after the last dspi_process): work items per launch list, counts[5] =
+ * {Q28 shared image, packed float shared image, one-stream kernel with per-lane parameter images, packed float with per-lane values
+ * incl. band coefficients, packed float with per-lane values and shared band coefficients}.  Tests use it to prove that a scenario
+ * ran on the path it was written for.  Returns 5 or a negative DSPI_E_*. */
+int dspi_debug_launch_plan(dspi_ctx *ctx, uint32_t *counts, size_t n_counts);
 
 /* Per-band taps of one EQ channel (float flavour; the parity procedure of SURVEY.md section 8d).  x[n] is run through the ten bands
  * of `channel` (0-1 master, 2.. outputs) of `stream`'s current parameters from zero state, band-major like the firmware's block loop

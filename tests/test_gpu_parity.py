@@ -183,6 +183,8 @@ def test_per_stream_presets_and_clip_flags():
         rp, rs, rk, _ = o[s].process(pcm[s], 20, B)
         assert np.array_equal(rp, pairs[s]) and np.array_equal(rs, sub[s]) and np.array_equal(rk, peaks[s]), s
         assert o[s].status() == d.status(s)
+    plan = d.launch_plan()      # 70 streams = one row of five images that differ in a preamp: the packed kernel with per-lane values, shared filters
+    assert plan["packed_per_lane_values"] == 1 and plan["packed_shared"] == 0 and plan["one_stream_per_lane_images"] == 0, plan
     flags = int.from_bytes(d.status(19)[-2:], "little")          # stream class 19 = full-scale square
     assert flags != 0 and d.clear_clips(19) == flags and int.from_bytes(d.status(19)[-2:], "little") == 0
     assert int.from_bytes(d.status(18)[-2:], "little") == int.from_bytes(o[18].status()[-2:], "little")
@@ -248,7 +250,7 @@ def test_one_structure_different_numbers(fma, fs, B, depth, S, lev):
             ch, band = int(rng.integers(0, 11)), int(rng.integers(0, 10))
             p = blob["eq"][ch][band]
             if int(p["type"]) == W.FILTER_FLAT: continue
-            reqs.append((R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, band, int(p["type"]), 0, float(p["freq"]), float(rng.uniform(0.5, 3.0)), float(rng.uniform(-9, 9)) or 1.0)))
+            reqs.append((R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, band, int(p["type"]), 0, float(p["freq"]), float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 9.0)) * (1.0 if rng.random() < 0.5 else -1.0))))      # |gain| < 0.01 dB would make the band flat: another structure
         o_ = int(rng.integers(0, 9))
         reqs.append((R["SET_OUTPUT_GAIN"], o_, f(float(rng.uniform(-12, 3)))))
         for i_ in range(2):       # a routed crosspoint keeps a non-zero gain (its zero pattern is structure)
@@ -278,6 +280,11 @@ def test_one_structure_different_numbers(fma, fs, B, depth, S, lev):
                 assert x(R["SET_OUTPUT_MUTE"], 2, b"\x01") == 0
         chunk = np.ascontiguousarray(data[:, call * per:(call + 1) * per])
         pairs, sub, peaks = d.process_host(chunk, blocks, B, depth)
+        plan = d.launch_plan()
+        rows = (S + 127) // 128
+        # row 0 holds the stream of another structure: it runs on the one-stream kernel; every other row is a per-lane-value row with
+        # per-lane filters; an odd last stream adds one more one-stream item
+        assert plan["packed_per_lane_values_and_bands"] == rows - 1 and plan["one_stream_per_lane_images"] >= 1 and plan["packed_shared"] == 0, plan
         for s_ in range(S):
             rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B, depth)
             assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (call, s_)
