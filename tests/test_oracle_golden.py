@@ -63,3 +63,24 @@ def test_q28_limiter_cast_is_the_documented_divergence():
     (p1, _, _, _), _ = run(g, x86=True)
     (p2, _, _, _), _ = run(g, x86=False)
     assert not np.array_equal(p1, p2)
+
+
+def test_q28_limiter_in_range_vector_engages_the_limiter():
+    """q28_limiter_in_range (generated from the reference's x86 build, valid because the limiter's cast stays in range on every sample):
+    in the quiet part the leveller boosts (meter above the input level) and the limiter leaves the gain alone; in the loud part the
+    gain is still above unity (an upward leveller never goes below it) and the limiter caps it to exactly unity on every sample —
+    the master meter reads the input level itself."""
+    g = np.load([p for p in GOLDEN if "q28_limiter_in_range" in p][0])
+    (_, _, peaks, _), _ = run(g, x86=False)
+    pcm = g["pcm"]
+    quiet, loud = int(abs(int(pcm[0, 0]))), int(abs(int(pcm[-1, 0])))
+    unity = lambda a: (a << 14) >> 13              # the meter's reading of a sample that went through with gain 1.0 (usb_audio.c:1279-1282)
+    assert peaks[699, 0] > unity(quiet) * 1.05                       # boosted
+    assert (peaks[720:, 0] == unity(loud)).all()                     # capped to unity, sample by sample
+    # the same input with the leveller off reads the same in the loud part (gain 1.0) and the unboosted level in the quiet part
+    from dspi_amd import wire as W
+    o = Oracle(0, detmath=True)
+    o.set_rate(int(g["fs"])); o.set_volume(int(g["volume"])); assert o.load_bulk(g["blob"].tobytes()) == 0
+    o.vendor_set(W.REQ["SET_LEVELLER_ENABLE"], 0, b"\x00")
+    _, _, pk_off, _ = o.process(pcm, int(g["blocks"]), int(g["block_len"]), 16)
+    assert pk_off[699, 0] == unity(quiet) and pk_off[-1, 0] == unity(loud)
