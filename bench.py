@@ -344,8 +344,9 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
             for s in range(S):
                 ctx.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s), stream=s)
                 if w["perstream"] == "eq":
-                    p = w["blob"]["eq"][0][0]
-                    ctx.vendor_set(W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", 0, 0, int(p["type"]), 0, float(p["freq"]), float(p["q"]), 1.0 + 0.0001 * s), stream=s)
+                    ch = int(os.environ.get("DSPI_BENCH_EQ_CH", "0"))      # which channel's first band differs per stream (0-1 master, 2.. outputs)
+                    p = w["blob"]["eq"][ch][1]
+                    ctx.vendor_set(W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, 1, int(p["type"]), 0, float(p["freq"]), float(p["q"]), 1.0 + 0.0001 * s), stream=s)
         if inp not in pcm_cache:
             pcm_cache.clear()
             pcm_cache[inp] = synth_device(torch, dev, S, frames, FS, 1234 + rank, inp == "mix", first)

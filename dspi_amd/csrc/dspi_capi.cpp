@@ -382,7 +382,8 @@ int commit_params(dspi_ctx *c) {
             if ((rc = ensure(c, c->d_pv_rows, c->d_pv_rows_cap, (size_t)c->n_wg * 4))) return rc;
             HIPCK(c, hipStreamSynchronize(c->hs));      // no launch may still be reading the tiles or the row list
             HIPCK(c, hipMemcpy(c->d_pv_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
-            HIPCK(c, launch_pv_build(c->d_images, c->d_stream_image, c->d_pv_rows, (uint32_t)rows.size(), c->d_vals, c->n_streams, c->hs));
+            static const bool all_differ = getenv("DSPI_DEBUG") && (strtoul(getenv("DSPI_DEBUG"), nullptr, 0) & 1u);      // development switch (timing of the worst case)
+            HIPCK(c, launch_pv_build(c->d_images, c->d_stream_image, c->d_pv_rows, (uint32_t)rows.size(), c->d_vals, c->n_streams, all_differ, c->hs));
         }
     }
     return 0;

@@ -77,6 +77,7 @@ struct DevImage {
 // their numbers.  Lane l holds streams 2l (a) and 2l+1 (b) of the row; every access below is one coalesced row per wave.
 //   bands    float4 [kPvBandSlots][3][64 lanes] = {c[2j].a, c[2j].b, c[2j+1].a, c[2j+1].b}   slot = ch*kBands + band, then loud[0..1]
 //   scalars  float2 [PV_COUNT][64 lanes]        = {value of a, value of b}
+//   mask     4 words: which band slots differ between the row's streams at all
 // ------------------------------------------------------------------------------------------
 constexpr int kPvBandSlots = kMaxCh * kBands + 2;
 enum PvScalar : int {
@@ -89,7 +90,9 @@ enum PvScalar : int {
     PV_COUNT = PV_XF + 3,
 };
 constexpr int kPvBandFloats = kPvBandSlots * 3 * kLanes * 4;            // 86 016
-constexpr int kPvTileFloats = kPvBandFloats + PV_COUNT * kLanes * 2;    // 91 648 floats = 366 592 bytes per row
+constexpr int kPvMaskWord = kPvBandFloats + PV_COUNT * kLanes * 2;      // 4 words: bit (slot) set = the band's coefficients DIFFER between the
+                                                                        // row's streams; a channel whose ten bits are clear runs on the image's scalars
+constexpr int kPvTileFloats = kPvMaskWord + 64;                         // 91 712 floats = 366 848 bytes per row
 
 // ------------------------------------------------------------------------------------------
 // Per-stream state: [workgroup][slot][lane] 32-bit words.  Slots 0..lds_slots-1 are staged in

@@ -39,7 +39,9 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
                             uint32_t *ring, uint32_t n_streams, hipStream_t stream);
 // (re)build the value tiles of the listed rows from the images of their streams
-hipError_t launch_pv_build(const DevImage *img, const uint32_t *stream_image, const uint32_t *rows, uint32_t n_rows, float *vals, uint32_t n_streams, hipStream_t stream);
+// all_differ: development switch, every band is treated as different between the row's streams (the worst case, for timing)
+hipError_t launch_pv_build(const DevImage *img, const uint32_t *stream_image, const uint32_t *rows, uint32_t n_rows, float *vals, uint32_t n_streams, bool all_differ,
+                           hipStream_t stream);
 hipError_t launch_state_init(int flavor, uint32_t *state, uint32_t n_wg, hipStream_t stream);
 // debug: taps [kBands+1][n] after every band of EQ channel `ch` of *img (float flavour), other [kBands][n] = the other
 // contract's one-step result from the same input and state

@@ -1519,6 +1519,10 @@ static hipError_t launch_chain_pk(const KArgs &args, bool leveller_on, uint32_t 
 }
 
 // ---- value tiles of the per-lane-value rows (dspi_image.h): one thread per (row, word, column) ----
+__global__ void pv_clear_kernel(const uint32_t *rows, float *vals, uint32_t all_differ) {
+    uint32_t *mask = reinterpret_cast<uint32_t *>(vals + (size_t)rows[blockIdx.x] * kPvTileFloats + kPvMaskWord);
+    if (threadIdx.x < 4) mask[threadIdx.x] = all_differ ? 0xffffffffu : 0u;
+}
 __global__ __launch_bounds__(256) void pv_build_kernel(const DevImage *img, const uint32_t *stream_image, const uint32_t *rows, float *vals, uint32_t n_streams) {
     constexpr int kWords = kPvBandSlots * 6 + PV_COUNT;
     const uint32_t wg = rows[blockIdx.y];
@@ -1532,7 +1536,13 @@ __global__ __launch_bounds__(256) void pv_build_kernel(const DevImage *img, cons
     size_t dst;
     if (w < (uint32_t)kPvBandSlots * 6u) {
         const uint32_t slot = w / 6u, k = w % 6u;
-        if (im) v = (slot < (uint32_t)(kMaxCh * kBands)) ? im->eq[slot / kBands][slot % kBands].c[k].f : im->loud[slot - kMaxCh * kBands].c[k].f;
+        if (im) {
+            auto coef = [&](const DevImage *m) { return (slot < (uint32_t)(kMaxCh * kBands)) ? m->eq[slot / kBands][slot % kBands].c[k].u : m->loud[slot - kMaxCh * kBands].c[k].u; };
+            const uint32_t bits = coef(im);
+            v = __builtin_bit_cast(float, bits);
+            // a band whose coefficient words are the same in every stream of the row can run on the image's scalars (value-tile mask)
+            if (bits != coef(img + stream_image[wg * 128u])) atomicOr(reinterpret_cast<uint32_t *>(tile + kPvMaskWord) + (slot >> 5), 1u << (slot & 31u));
+        }
         dst = ((size_t)(slot * 3u + (k >> 1)) * kLanes + (col >> 1)) * 4u + (k & 1u) * 2u + (col & 1u);
     } else {
         const int s = (int)w - kPvBandSlots * 6;
@@ -1552,9 +1562,11 @@ __global__ __launch_bounds__(256) void pv_build_kernel(const DevImage *img, cons
     tile[dst] = v;
 }
 
-hipError_t launch_pv_build(const DevImage *img, const uint32_t *stream_image, const uint32_t *rows, uint32_t n_rows, float *vals, uint32_t n_streams, hipStream_t stream) {
+hipError_t launch_pv_build(const DevImage *img, const uint32_t *stream_image, const uint32_t *rows, uint32_t n_rows, float *vals, uint32_t n_streams, bool all_differ,
+                           hipStream_t stream) {
     constexpr int kWords = kPvBandSlots * 6 + PV_COUNT;
     if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(pv_clear_kernel, dim3(n_rows), dim3(64), 0, stream, rows, vals, all_differ ? 1u : 0u);
     hipLaunchKernelGGL(pv_build_kernel, dim3((kWords * 128 + 255) / 256, n_rows), dim3(256), 0, stream, img, stream_image, rows, vals, n_streams);
     return hipGetLastError();
 }
