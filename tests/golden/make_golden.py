@@ -32,6 +32,10 @@ CASES = [
     # and leaves the gain alone), then -6 dBFS (gain still above 1 while it decays: the limiter caps it to unity on every sample).
     # Master EQ, loudness and preamp are flat in this preset — ringing would put near-zero samples next to a gain above 1.
     ("q28_limiter_in_range", 0, 48000, 48, 760, "limiter_blob", -20 * 256, 16, True, "limiter_pcm"),
+    # the firmware's float contract: the same leaf sources compiled with GCC's contraction (oracle/_ref/libref_f32_fma.so)
+    ("f32fma_full_96k_detmath", W.F32_FMA, 96000, 96, 40, lambda: WL.full_chain_blob(1), -20 * 256, 16, True, 3),
+    ("f32fma_full_441_24bit_detmath", W.F32_FMA, 44100, 45, 30, lambda: WL.full_chain_blob(1), -6 * 256, 24, True, 16),
+    ("f32fma_config2_svf_biquad", W.F32_FMA, 48000, 48, 40, lambda: WL.config2_blob(False), -10 * 256, 16, False, 0),
 ]
 
 
@@ -73,7 +77,7 @@ def main():
         status = np.frombuffer(o.status(), dtype=np.uint8)
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),
-            flavor=flavor, fs=fs, block_len=B, blocks=blocks, volume=vol, bit_depth=depth, detmath=int(detmath), first_stream=(-1 if isinstance(first, str) else first),
+            flavor=int(flavor), fma=int(bool(getattr(flavor, "fma", False))), fs=fs, block_len=B, blocks=blocks, volume=vol, bit_depth=depth, detmath=int(detmath), first_stream=(-1 if isinstance(first, str) else first),
             blob=np.frombuffer(blob.tobytes(), dtype=np.uint8), pcm=data,
             pairs_crc=summarise(pairs), sub_crc=summarise(sub), peaks_crc=summarise(peaks), clip=np.uint16(clip), status=status,
             pairs_head=pairs[:, :96], pairs_tail=pairs[:, -96:], sub_head=sub[:96], sub_tail=sub[-96:], peaks=peaks)

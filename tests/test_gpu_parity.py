@@ -363,7 +363,7 @@ def test_golden_fixtures_on_gpu(path):
     if "q28_full_48k_detmath" in path:
         pytest.skip("golden encodes the x86 INT_MIN cast artefact of the reference build; GPU follows the firmware (saturating)")
     flavor = int(g["flavor"])
-    d = Dspi(flavor, 1, device=0)
+    d = Dspi(flavor, 1, device=0, fma=bool(int(g["fma"])) if "fma" in g else False)      # f32fma_*: the reference compiled with GCC's contraction
     d.set_rate(int(g["fs"])); d.set_volume(int(g["volume"])); assert d.load_bulk(g["blob"].tobytes()) == 0
     data = g["pcm"][None]
     pairs, sub, peaks = d.process_host(np.ascontiguousarray(data), int(g["blocks"]), int(g["block_len"]), int(g["bit_depth"]))

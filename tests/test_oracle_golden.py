@@ -21,7 +21,7 @@ def crc(a):
 
 
 def run(g, x86):
-    o = Oracle(int(g["flavor"]), ref=False, detmath=bool(g["detmath"]), x86_casts=x86)
+    o = Oracle(int(g["flavor"]), ref=False, detmath=bool(g["detmath"]), x86_casts=x86, fma=bool(int(g["fma"])) if "fma" in g else False)
     assert o.set_rate(int(g["fs"])) == 0
     o.set_volume(int(g["volume"]))
     assert o.load_bulk(g["blob"].tobytes()) == 0
