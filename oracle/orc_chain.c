@@ -1182,7 +1182,8 @@ int orc_load_preset_slot(orc_ctx *c, const void *image, uint32_t len, int expect
 
 /* ---- flash dump: directory, startup-slot selection, legacy migration ----
  * flash_storage.c:95-131 (directory v1 / v2), :370-417 (dir_load_cache), :997-1045 (migrate_legacy), :1047-1105
- * (preset_boot_load).  flash_storage.c needs pico-sdk (hardware/flash.h): restated, PARITY UNPINNED; the slot payloads
+ * (preset_boot_load).  Restated here; PINNED by the firmware build (ref_fw_flash.c compiles flash_storage.c in place over a RAM
+ * flash: tests/test_oracle_vs_fw.py::test_boot_from_flash_dumps, ::test_legacy_sector_migration); the slot payloads
  * go through orc_load_preset_slot, i.e. the selection is the boot path's and the application is preset_load's. */
 typedef struct __attribute__((packed)) {
     uint32_t magic; uint16_t version; uint16_t reserved; uint32_t crc32;

@@ -4,9 +4,10 @@
  *
  * TEST INFRASTRUCTURE ONLY (same rules as the rest of oracle/): never linked into or imported by the product.
  *
- * PARITY UNPINNED: pdm_generator.c includes pico-sdk hardware headers (PIO/DMA) and cannot be compiled here, and the
- * reference ships no vectors for it; this file restates the arithmetic of the per-sample path line by line and is
- * checked by analytical identities (tests/test_oracle_pdm.py): DC bit density, silence pattern, fade-in length.
+ * PINNED: pdm_generator.c itself is compiled in place over a host stand-in for the pico-sdk in the firmware build of the oracle
+ * (ref_fw_core1.c: pdm_processing_loop runs as a coroutine with an emulated DMA read pointer) and this restatement reproduces
+ * its words bit for bit (tests/test_oracle_vs_fw.py::test_pdm_modulator_is_pdm_processing_loop); the reference ships no vectors,
+ * analytical identities are in tests/test_oracle_pdm.py (DC bit density, silence pattern, fade-in length).
  *
  * What is restated (per input sample, in this order):
  *   hard limiter  pcm = sample >> 14, clamp to +-PDM_CLIP_THRESH            pdm_generator.c:351-354, config.h:64
