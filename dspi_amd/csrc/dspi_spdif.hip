@@ -92,6 +92,28 @@ __global__ __launch_bounds__(256) void spdif_kernel_frames(const int32_t *pairs,
     *reinterpret_cast<u4 *>(out + idx * 4) = u4{l0, h0, l1, h1};
 }
 
+// even frame counts: two frames per lane (16 bytes in, 32 bytes out)
+__global__ __launch_bounds__(256) void spdif_kernel_frames2(const int32_t *pairs, uint32_t *out, uint64_t total2, uint32_t half_frames, uint32_t block_pos,
+                                                           uint32_t status_lo, uint32_t status_hi) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;      // (stream * n_pairs + pair) * (n_frames / 2) + frame pair
+    if (idx >= total2) return;
+    const uint32_t f = (uint32_t)(idx % half_frames) * 2u;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 w = *reinterpret_cast<const u4 *>(pairs + idx * 4);
+    u4 o[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t pos = (block_pos + f + k) % 192u;
+        const uint32_t c_bit = pos < 32 ? (status_lo >> pos) & 1u : (pos < 40 ? (status_hi >> (pos - 32)) & 1u : 0u);
+        uint32_t l0, h0, l1, h1;
+        subframe(k ? w.z : w.x, pos == 0 ? 0x39u : 0xC9u, c_bit, l0, h0);
+        subframe(k ? w.w : w.y, 0x69u, c_bit, l1, h1);
+        o[k] = u4{l0, h0, l1, h1};
+    }
+    *reinterpret_cast<u4 *>(out + idx * 8) = o[0];
+    *reinterpret_cast<u4 *>(out + idx * 8 + 4) = o[1];
+}
+
 // ---- I2S slots: pico_audio_i2s_multi/audio_i2s_multi.c:217-226 — the same producer words left-justified (<< 8), L then R.
 // 8 bytes in, 8 bytes out per frame: a pure copy-with-shift at memory speed.  Pairs outside `pair_mask` are not touched.
 __global__ __launch_bounds__(256) void i2s_kernel_frames(const int32_t *pairs, uint32_t *out, uint64_t total, uint32_t n_frames, uint32_t n_pairs, uint32_t pair_mask) {
@@ -102,6 +124,16 @@ __global__ __launch_bounds__(256) void i2s_kernel_frames(const int32_t *pairs, u
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
     const u2 w = *reinterpret_cast<const u2 *>(pairs + idx * 2);
     *reinterpret_cast<u2 *>(out + idx * 2) = u2{w.x << 8, w.y << 8};
+}
+// even frame counts: two frames (16 bytes) per lane
+__global__ __launch_bounds__(256) void i2s_kernel_frames2(const int32_t *pairs, uint32_t *out, uint64_t total2, uint32_t half_frames, uint32_t n_pairs, uint32_t pair_mask) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;      // (stream * n_pairs + pair) * (n_frames / 2) + frame pair
+    if (idx >= total2) return;
+    const uint32_t pair = (uint32_t)((idx / half_frames) % n_pairs);
+    if (!((pair_mask >> pair) & 1u)) return;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 w = *reinterpret_cast<const u4 *>(pairs + idx * 4);
+    *reinterpret_cast<u4 *>(out + idx * 4) = u4{w.x << 8, w.y << 8, w.z << 8, w.w << 8};
 }
 // tiled: [tile][output][frame][R] words, R a multiple of 4: one lane per 4 streams of one (output, frame)
 __global__ __launch_bounds__(256) void i2s_kernel_tiled(const int32_t *pairs, uint32_t *out, uint64_t total4, uint64_t plane_words, uint32_t n_out, uint32_t pair_mask) {
@@ -123,7 +155,8 @@ hipError_t launch_i2s(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t 
         hipLaunchKernelGGL(i2s_kernel_tiled, dim3((uint32_t)((total4 + 255) / 256)), dim3(256), 0, stream, pairs, out, total4, plane, 2 * n_pairs, pair_mask);
     } else {
         const uint64_t total = (uint64_t)n_streams * n_pairs * n_frames;
-        hipLaunchKernelGGL(i2s_kernel_frames, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pairs, out, total, n_frames, n_pairs, pair_mask);
+        if (n_frames % 2 == 0) hipLaunchKernelGGL(i2s_kernel_frames2, dim3((uint32_t)((total / 2 + 255) / 256)), dim3(256), 0, stream, pairs, out, total / 2, n_frames / 2, n_pairs, pair_mask);
+        else hipLaunchKernelGGL(i2s_kernel_frames, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pairs, out, total, n_frames, n_pairs, pair_mask);
     }
     return hipGetLastError();
 }
@@ -136,7 +169,8 @@ hipError_t launch_spdif(bool tiled, const int32_t *pairs, uint32_t *out, uint32_
     if (tiled) hipLaunchKernelGGL(spdif_kernel<true>, dim3(n_wg, n_pairs, (n_frames + kFrameSlice - 1) / kFrameSlice), dim3(128), 0, stream, pairs, out, n_streams, n_pairs, n_frames, row, block_pos, lo, hi);
     else {
         const uint64_t total = (uint64_t)n_streams * n_pairs * n_frames;
-        hipLaunchKernelGGL(spdif_kernel_frames, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pairs, out, total, n_frames, block_pos, lo, hi);
+        if (n_frames % 2 == 0) hipLaunchKernelGGL(spdif_kernel_frames2, dim3((uint32_t)((total / 2 + 255) / 256)), dim3(256), 0, stream, pairs, out, total / 2, n_frames / 2, block_pos, lo, hi);
+        else hipLaunchKernelGGL(spdif_kernel_frames, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pairs, out, total, n_frames, block_pos, lo, hi);
     }
     return hipGetLastError();
 }

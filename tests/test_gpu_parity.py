@@ -494,6 +494,9 @@ def test_spdif_subframes(flavor):
                 for p_ in range(P):
                     ref, n2 = orclib.spdif_encode(pairs[s_, p_], pos, fs)
                     assert n2 == nxt and np.array_equal(ref, sf[s_, p_]), (fs, c, s_, p_)
+            # an odd frame count takes the one-frame-per-lane kernel (even counts: two frames per lane): same subframes
+            sf_odd, n_odd = d.spdif_host(np.ascontiguousarray(pairs[:, :, :F - 1]), pos)
+            assert n_odd == (pos + F - 1) % 192 and np.array_equal(sf_odd, sf[:, :, :F - 1])
             pos = nxt
         d.close(); dt.close()
 
@@ -529,6 +532,10 @@ def test_i2s_slot_words(flavor):
     assert m == 0b10
     wt = wt.transpose(0, 3, 1, 2).reshape(nt * R, P, 2, F).transpose(0, 1, 3, 2)[:S]
     assert np.array_equal(wt[:, 1], words[:, 1]) and not wt[:, 0].any()
+    even = np.ascontiguousarray(pairs[:, :, :F - 1])                       # an even frame count takes the two-frames-per-lane kernel
+    we, m = d.i2s_host(even, pair_mask=0b101 if P > 2 else 0b01, out=keep[:, :, :F - 1].copy())
+    sel = [0, 2] if P > 2 else [0]
+    assert np.array_equal(we[:, sel], even[:, sel].view(np.uint32) << 8) and np.array_equal(np.delete(we, sel, axis=1), np.delete(keep[:, :, :F - 1], sel, axis=1))
     assert d.L.dspi_i2s_encode(d.h, pairs.ctypes.data, F, 1 << P, words.ctypes.data, 0) == -10    # DSPI_E_INVAL: no such pair
     d.close()
 
