@@ -397,6 +397,8 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
              "hbm_fraction_measured_traffic": (prof["hbm_bytes_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof else None,
              "valu_fraction": (prof["valu_insts_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS) if prof and prof["valu_insts_per_frame"] else None,
              "binds": "valu"}
+        # what binds: the bytes actually moved (profiles/) against the practical ceiling of this memory system (~6 TB/s), else issue
+        if r["hbm_fraction_measured_traffic"] and r["hbm_fraction_measured_traffic"] >= 0.70: r["binds"] = "memory (bytes moved at the L2-fabric boundary)"
         return r
 
     if flavor == 1:
