@@ -23,6 +23,9 @@ def run(label, blob, outputs=True, steps=4):
         import struct
         for s_ in range(S):
             d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s_), stream=s_)
+            if os.environ.get('PERSTREAM') == 'eq':      # a band's gain per stream as well: per-lane filters (DSPI_DEBUG=1: every band)
+                ch = int(os.environ.get('EQ_CH', 0)); p = blob['eq'][ch][1]
+                d.vendor_set(W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, 1, int(p['type']), 0, float(p['freq']), float(p['q']), 1.0 + 0.0001 * s_), stream=s_)
     args = (pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr()) if outputs else (0, 0, 0)
     d.process_device(pcm.data_ptr(), NB, B, 16, *args, tiled=TILED); d.sync()
     t0 = time.perf_counter()
