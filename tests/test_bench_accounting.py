@@ -1,0 +1,57 @@
+"""bench.py's byte accounting and input generator, on CPU: the algorithmic bytes per frame of every chain config (SURVEY.md section 8d:
+both the HBM-resident-delay-line figure the roofline fraction uses and the launch-span figure), the profile lookup by kernel variant,
+and the stream classes of the synthetic mix."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("dspi_bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_algorithmic_bytes():
+    w = bench.chain_workload("3")
+    full, span = bench.algorithmic_bytes(w, 50 * 96)
+    assert full == 104.0                          # 4 in + 8 x 4 S/PDIF words + 4 sub + 8 x 8 delayed outputs (write + read)
+    assert 55.0 < span < 65.0                     # delays shorter than the 4 800-frame launch count only dly/T of their 8 bytes
+    assert bench.algorithmic_bytes(w, 10 ** 9)[1] < 41.0 and bench.algorithmic_bytes(w, 1)[1] == full
+    assert bench.algorithmic_bytes(bench.chain_workload("2"), 2000 * 48) == (12.0, 12.0)
+    q = bench.chain_workload("5")
+    assert bench.algorithmic_bytes(q, 50 * 48)[0] == 56.0      # 4 in + 4 x 4 words + 4 sub + 4 x 8 delayed outputs
+    for name in ("perstream", "perstream_eq"):
+        assert bench.algorithmic_bytes(bench.chain_workload(name), 50 * 96)[0] == 104.0
+
+
+def test_profile_lookup_matches_the_variant():
+    found = 0
+    for key, contract, layout in (("chain3", "fma", "stream"), ("chain3", "fma", "tiled"), ("chain3", "canonical", "tiled"), ("chain5", "integer", "stream"),
+                                  ("perstream", "fma", "stream")):
+        p = bench.latest_profile(key, contract, layout)
+        if p is None: continue
+        found += 1
+        t = json.load(open(os.path.join(ROOT, "profiles", p["source"])))
+        assert t.get("kernel_key", "chain3") == key and t.get("contract", "canonical") == contract and t.get("out_layout", "stream") == layout
+        assert 50.0 < p["hbm_bytes_per_frame"] < 400.0
+    assert found >= 3
+    assert bench.latest_profile("no-such-kernel", "fma", "stream") is None
+
+
+def test_synthetic_mix_classes():
+    fs, frames, S = 96000, 4800, 40
+    pcm = bench.synth_device(torch, torch.device("cpu"), S, frames, fs, 7, True).numpy()
+    assert pcm.shape == (S, frames, 2) and pcm.dtype == np.int16
+    assert np.abs(pcm[0]).max() <= 16384 and np.abs(pcm[0]).max() > 12000            # white noise at -6 dBFS
+    assert not pcm[18].any() and not pcm[38].any()                                    # digital silence
+    assert set(np.unique(pcm[19, :, 0]).tolist()) == {-32768, 32767}                  # full-scale square
+    assert np.abs(pcm[16, :frames // 2]).max() < 1100 < np.abs(pcm[16, frames // 2:]).max()      # bursts: -30 dBFS then -6 dBFS
+    assert 8000 < np.abs(pcm[14]).max() <= 8231                                       # sweep at -12 dBFS
+    shifted = bench.synth_device(torch, torch.device("cpu"), 4, frames, fs, 7, True, first_stream=16).numpy()
+    assert not shifted[2].any()                                                       # classes follow the GLOBAL stream index (shards)
+    noise = bench.synth_device(torch, torch.device("cpu"), S, frames, fs, 7, False).numpy()
+    assert noise[18].any()
