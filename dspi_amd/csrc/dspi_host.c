@@ -6,7 +6,7 @@
  * blob from a file, feeds interleaved PCM through dspi_process() in packets, prints throughput
  * and the status block of stream 0.  Everything DSP happens behind the C-ABI (include/dspi.h).
  *
- *   dspi_host [-f q28|f32] [-s streams] [-r rate] [-b block_len] [-n blocks] [-c calls]
+ *   dspi_host [-f q28|f32|f32fma] [-s streams] [-r rate] [-b block_len] [-n blocks] [-c calls]
  *             [-B bulk.bin | -P slot.bin] [-i pcm16le.raw] [-o pairs.raw] [-v volume_db]
  */
 #include <math.h>
@@ -39,7 +39,9 @@ int main(int argc, char **argv) {
     double vol_db = 0.0;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i], *v = (i + 1 < argc) ? argv[i + 1] : NULL;
-        if (!strcmp(a, "-f") && v) { flavor = !strcmp(v, "q28") ? DSPI_FLAVOR_RP2040_Q28 : DSPI_FLAVOR_RP2350_F32; i++; }
+        if (!strcmp(a, "-f") && v) {      /* f32fma: the float flavour with the firmware build's fused multiply-adds (dspi.h) */
+            flavor = !strcmp(v, "q28") ? DSPI_FLAVOR_RP2040_Q28 : (!strcmp(v, "f32fma") ? DSPI_FLAVOR_RP2350_F32_FMA : DSPI_FLAVOR_RP2350_F32); i++;
+        }
         else if (!strcmp(a, "-s") && v) { streams = (uint32_t)atoi(v); i++; }
         else if (!strcmp(a, "-r") && v) { rate = (uint32_t)atoi(v); i++; }
         else if (!strcmp(a, "-b") && v) { block_len = (uint32_t)atoi(v); i++; }
@@ -50,7 +52,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "-i") && v) { in = v; i++; }
         else if (!strcmp(a, "-o") && v) { outp = v; i++; }
         else if (!strcmp(a, "-v") && v) { vol_db = atof(v); i++; }
-        else { fprintf(stderr, "usage: %s [-f q28|f32] [-s streams] [-r rate] [-b block_len] [-n blocks] [-c calls] [-B bulk.bin|-P slot.bin] [-i pcm.raw] [-o pairs.raw] [-v vol_db]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [-f q28|f32|f32fma] [-s streams] [-r rate] [-b block_len] [-n blocks] [-c calls] [-B bulk.bin|-P slot.bin] [-i pcm.raw] [-o pairs.raw] [-v vol_db]\n", argv[0]); return 2; }
     }
     dspi_ctx *ctx = NULL;
     int rc = dspi_create(&ctx, flavor, streams, 0);

@@ -9,14 +9,14 @@ import pytest
 
 from conftest import has_gpu
 from orclib import Oracle
-from dspi_amd import workloads as WL
+from dspi_amd import wire as W, workloads as WL
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no GPU")]
 
 HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dspi_amd", "csrc", "dspi_host")
 
 
-@pytest.mark.parametrize("flavor,load", [(1, "slot"), (1, "bulk"), (0, "slot")])
+@pytest.mark.parametrize("flavor,load", [(1, "slot"), (1, "bulk"), (W.F32_FMA, "slot"), (0, "slot")])
 def test_dspi_host_against_oracle(tmp_path, flavor, load):
     fs, B, blocks, calls, vol_db = 48000, 48, 20, 3, -20
     ref = Oracle(flavor); assert ref.load_bulk(WL.full_chain_blob(flavor)) == 0
@@ -24,7 +24,7 @@ def test_dspi_host_against_oracle(tmp_path, flavor, load):
     pcm = WL.synth_pcm16(1, B * blocks, fs, first_stream=3)[0]
     (tmp_path / "preset.bin").write_bytes(image)
     (tmp_path / "pcm.raw").write_bytes(np.ascontiguousarray(pcm).tobytes())
-    r = subprocess.run([HOST, "-f", "f32" if flavor else "q28", "-s", "70", "-r", str(fs), "-b", str(B), "-n", str(blocks), "-c", str(calls),
+    r = subprocess.run([HOST, "-f", ("f32fma" if getattr(flavor, "fma", False) else "f32") if flavor else "q28", "-s", "70", "-r", str(fs), "-b", str(B), "-n", str(blocks), "-c", str(calls),
                         "-P" if load == "slot" else "-B", str(tmp_path / "preset.bin"), "-i", str(tmp_path / "pcm.raw"), "-o", str(tmp_path / "pairs.raw"), "-v", str(vol_db)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
