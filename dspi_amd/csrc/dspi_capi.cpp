@@ -16,6 +16,9 @@
 #include <string>
 #include <map>
 #include <vector>
+#include <thread>
+#include <xmmintrin.h>
+#include <algorithm>
 
 #include "../../include/dspi.h"
 #include "dspi_image.h"
@@ -327,31 +330,46 @@ int commit_params(dspi_ctx *c) {
         dspi_ctx::ImageSig none; memset(&none, 0xff, sizeof none);
         c->image_sig.resize(ni, none); c->image_bands.resize(ni, dspi_ctx::BandHash{0, 0}); c->image_touched.resize(ni, 1); c->launch_dirty = true;
     }
+    // a run of dirty images: built on all host threads when it is long (every stream its own preset: tens of thousands at once),
+    // compared with what the launch lists were built from, uploaded with one copy
     std::vector<DevImage> run;
-    size_t run0 = 0;
-    auto flush = [&]() -> int {
-        if (!run.empty()) HIPCK(c, hipMemcpy(c->d_images + run0, run.data(), run.size() * sizeof(DevImage), hipMemcpyHostToDevice));
-        run.clear();
-        return 0;
-    };
-    for (size_t i = 0; i < ni; i++) {
-        Params &p = *c->images[i];
-        if (!p.dirty) { int rc = flush(); if (rc) return rc; continue; }
-        if (run.empty()) run0 = i;
-        run.emplace_back();
-        p.build_image(run.back());
-        if ((c->image_flags[i] ^ run.back().flags) & IF_LEVELLER_ON) c->launch_dirty = true;
-        c->image_flags[i] = run.back().flags;
-        if (c->flavor) {
-            const dspi_ctx::ImageSig sig = make_sig(run.back());
-            if (memcmp(&sig, &c->image_sig[i], sizeof sig) != 0) { c->image_sig[i] = sig; c->launch_dirty = true; }
-            const dspi_ctx::BandHash bh = hash_bands(run.back());
-            if (bh.a != c->image_bands[i].a || bh.b != c->image_bands[i].b) { c->image_bands[i] = bh; c->launch_dirty = true; }
-            c->image_touched[i] = 1;
+    std::vector<dspi_ctx::ImageSig> run_sig;
+    std::vector<dspi_ctx::BandHash> run_bands;
+    for (size_t i = 0; i < ni;) {
+        if (!c->images[i]->dirty) { i++; continue; }
+        size_t j = i;
+        while (j < ni && c->images[j]->dirty) j++;
+        const size_t n = j - i;
+        run.resize(n);
+        if (c->flavor) { run_sig.resize(n); run_bands.resize(n); }
+        const unsigned csr = _mm_getcsr();      // the workers round and flush exactly like the calling thread
+        auto build = [&](size_t k0, size_t k1) {
+            _mm_setcsr(csr);
+            for (size_t k = k0; k < k1; k++) {
+                c->images[i + k]->build_image(run[k]);
+                if (c->flavor) { run_sig[k] = make_sig(run[k]); run_bands[k] = hash_bands(run[k]); }
+            }
+        };
+        const size_t nt = n >= 512 ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(32, n / 128)) : 1;
+        if (nt > 1) {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < nt; t++) th.emplace_back(build, n * t / nt, n * (t + 1) / nt);
+            for (auto &x : th) x.join();
+        } else build(0, n);
+        for (size_t k = 0; k < n; k++) {
+            const size_t ii = i + k;
+            if ((c->image_flags[ii] ^ run[k].flags) & IF_LEVELLER_ON) c->launch_dirty = true;
+            c->image_flags[ii] = run[k].flags;
+            if (c->flavor) {
+                if (memcmp(&run_sig[k], &c->image_sig[ii], sizeof(dspi_ctx::ImageSig)) != 0) { c->image_sig[ii] = run_sig[k]; c->launch_dirty = true; }
+                if (run_bands[k].a != c->image_bands[ii].a || run_bands[k].b != c->image_bands[ii].b) { c->image_bands[ii] = run_bands[k]; c->launch_dirty = true; }
+                c->image_touched[ii] = 1;
+            }
+            c->images[ii]->dirty = false;
         }
-        p.dirty = false;
+        HIPCK(c, hipMemcpy(c->d_images + i, run.data(), n * sizeof(DevImage), hipMemcpyHostToDevice));
+        i = j;
     }
-    { int rc = flush(); if (rc) return rc; }
     // pending state mutations: consecutive images with the same mutation share one launch (their workgroup items are
     // consecutive in d_items, list 0)
     for (size_t i = 0; i < ni;) {
@@ -590,6 +608,7 @@ int dspi_debug_image(dspi_ctx *c, int32_t stream, void *buf, size_t cap) {
 int dspi_debug_launch_plan(dspi_ctx *c, uint32_t *counts, size_t n_counts) {
     if (!c || !counts || n_counts < 5) return DSPI_E_INVAL;
     for (int k = 0; k < 5; k++) counts[k] = (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size());
+    if (c->flavor) counts[0] = 0;      // (list 0 of a float context is bookkeeping for the state mutations, never launched)
     return 5;
 }
 
