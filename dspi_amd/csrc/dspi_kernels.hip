@@ -1465,7 +1465,7 @@ __global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
 size_t chain_lds_bytes(int flavor, int packed) {
     const StateMap sm = make_state_map(flavor);
     // Q28 one-stream kernel: + queued gain decisions, the posted right-channel envelope and the role table (kQ28Mail + 2 + 1 rows)
-    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox : (flavor ? 0 : 7))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);
+    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox + 2 : (flavor ? 0 : 7))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);      // packed: + role table (16 B) and the posted left envelope (2 rows)
 }
 
 constexpr int kMaxDevices = 65;      // slot 64: any device index beyond (attribute set on every launch)
