@@ -48,6 +48,8 @@ void orc_process(orc_ctx *, const void *pcm, int bit_depth, uint32_t n_blocks, u
 
 /* per-band taps of one EQ channel, float flavour: taps [11][n] (orc_chain.c) */
 int orc_debug_eq_taps(orc_ctx *, int channel, const float *x, uint32_t n, float *taps);
+/* Q28 builds only: the block biquad (dsp_process_rp2040.S:225-394 restated) on caller-supplied bands */
+void orc_debug_q28_biquad_block(const int32_t *coef, int32_t *state, const uint8_t *bypass, int32_t *x, uint32_t count, uint32_t nbands);
 
 /* debugging taps used by tests */
 const void *orc_tap(orc_ctx *, int what, int *bytes);

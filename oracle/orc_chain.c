@@ -260,6 +260,22 @@ static void q28_biquad_block(Biquad *bands, int32_t *x, uint32_t count, uint8_t 
 }
 #endif
 
+#if !PICO_RP2350
+/* test hook: the Q28 block biquad on caller-supplied bands (coef [nbands][5] = b0 b1 b2 a1 a2, state [nbands][2] in/out), so that it can be
+ * compared with the reference's assembly executed instruction by instruction (tests/thumb.py, tests/test_oracle_thumb.py) */
+void orc_debug_q28_biquad_block(const int32_t *coef, int32_t *state, const uint8_t *bypass, int32_t *x, uint32_t count, uint32_t nbands) {
+    Biquad bands[MAX_BANDS];
+    if (nbands > MAX_BANDS) nbands = MAX_BANDS;
+    memset(bands, 0, sizeof bands);
+    for (uint32_t b = 0; b < nbands; b++) {
+        bands[b].b0 = coef[b * 5]; bands[b].b1 = coef[b * 5 + 1]; bands[b].b2 = coef[b * 5 + 2]; bands[b].a1 = coef[b * 5 + 3]; bands[b].a2 = coef[b * 5 + 4];
+        bands[b].s1 = state[b * 2]; bands[b].s2 = state[b * 2 + 1]; bands[b].bypass = bypass[b] != 0;
+    }
+    q28_biquad_block(bands, x, count, (uint8_t)nbands);
+    for (uint32_t b = 0; b < nbands; b++) { state[b * 2] = bands[b].s1; state[b * 2 + 1] = bands[b].s2; }
+}
+#endif
+
 static void eq_block(orc_ctx *c, int ch, orc_sample *x, uint32_t n) {
 #if PICO_RP2350
 #if ORC_USE_REF
