@@ -16,13 +16,10 @@
  * headers are the reference's own.  One library instance = one device (the firmware keeps its state in
  * file-scope globals): tests load a private copy of the .so per stream.
  *
- * Restated here because main.c cannot be compiled (its loop body is one function with hardware bring-up):
- *   - the main-loop deferred-apply dispatcher        main.c:826-1162   -> fw_service()
- *   - perform_rate_change (DSP part)                 main.c:132-171
- *   - prepare_pipeline_reset / flash-write bracket   main.c:449-458, :553-575
- *   - the boot sequence after usb_sound_card_init    main.c:645-716
- *   - the ARM inline asm of the 24-bit float unpack  usb_audio.c:613-646, :657-675 (two statements)
- * and, for the Q28 flavour, the Thumb block biquad dsp_process_rp2040.S:225-394 (ref_fw_stubs.c).
+ * main.c (core0_init, the main loop with its deferred-apply dispatcher, rate changes, pipeline resets, output type switches) is
+ * compiled in place too and runs as a coroutine, one loop iteration per fw_main_step() (ref_fw_main.c).
+ * Restated here: the ARM inline asm of the 24-bit float unpack (usb_audio.c:613-646, :657-675, two statements) and, for the Q28
+ * flavour, the Thumb block biquad dsp_process_rp2040.S:225-394 (ref_fw_stubs.c; pinned by executing the assembly, tests/thumb.py).
  */
 #include <stdio.h>
 #include <string.h>
@@ -152,121 +149,15 @@ struct usb_device *usb_device_init(const struct usb_device_descriptor *desc, con
 void usb_device_start(void) {}
 
 /* ------------------------------------------------------------------------------------- */
-/* main.c, restated: the deferred-apply dispatcher                                         */
+/* main.c: compiled in place and run as a coroutine (ref_fw_main.c)                        */
 /* ------------------------------------------------------------------------------------- */
-static int fw_last_bulk_err, fw_last_preset_status;
+extern int fw_last_bulk_err, fw_last_preset_status;
+void fw_main_start(void);      /* power-on: main() up to the top of its loop (core0_init, boot preset) */
+void fw_main_step(void);       /* one iteration of the reference's main loop */
 static unsigned fw_enter(void) { unsigned c = _mm_getcsr(); _mm_setcsr(c | 0x8040u); return c; }   /* FPSCR.FZ, main.c:593-600 */
 static void fw_leave(unsigned c) { _mm_setcsr(c); }
-
-static void fw_prepare_pipeline_reset(uint32_t mute_samples) { /* main.c:449-458 */
-    preset_mute_counter = mute_samples;
-    preset_loading = true;
-}
-#define FLASH_WRITE_PREMUTE_MS 120u          /* main.c:543 */
-static void fw_prepare_flash_write(void) { /* main.c:546-575 */
-    uint64_t samples = ((uint64_t)audio_state.freq * (uint64_t)FLASH_WRITE_PREMUTE_MS + 999u) / 1000u;
-    if (samples < PRESET_MUTE_SAMPLES) samples = PRESET_MUTE_SAMPLES;
-    fw_prepare_pipeline_reset((uint32_t)samples);
-}
-static void fw_transition_core1(void) { /* main.c:1079-1086, :1151-1158 */
-    Core1Mode m = derive_core1_mode();
-    if (m != core1_mode) { core1_mode = m; pdm_set_enabled(m == CORE1_MODE_PDM); }
-}
-static void fw_perform_rate_change(uint32_t f) { /* main.c:132-171 */
-    switch (f) { case 44100: case 48000: case 96000: break; default: f = 44100; }
-    audio_format_48k.sample_freq = f;
-    sync_started = false; total_samples_produced = 0;
-    dsp_recalculate_all_filters((float)f);
-    loudness_recompute_pending = true; crossfeed_update_pending = true; leveller_update_pending = true;
-}
-
-static void fw_service(void) { /* main.c:738-1162, the branches that touch the DSP state */
-    if (flash_set_name_pending) { flash_set_name_pending = false; fw_prepare_flash_write(); preset_set_name(flash_set_name_slot, flash_set_name_buf); }
-    if (flash_set_startup_pending) { flash_set_startup_pending = false; fw_prepare_flash_write(); preset_set_startup(flash_set_startup_mode, flash_set_startup_slot); }
-    if (flash_set_include_pins_pending) { flash_set_include_pins_pending = false; fw_prepare_flash_write(); preset_set_include_pins(flash_set_include_pins_val); }
-    if (flash_set_master_volume_mode_pending) { flash_set_master_volume_mode_pending = false; fw_prepare_flash_write(); preset_set_master_volume_mode(flash_set_master_volume_mode_val); }
-    if (flash_save_master_volume_pending) { flash_save_master_volume_pending = false; fw_prepare_flash_write(); preset_save_master_volume(); }
-    if (eq_update_pending) { /* :826-857 */
-        EqParamPacket p = pending_packet;
-        eq_update_pending = false;
-        filter_recipes[p.channel][p.band] = p;
-        dsp_compute_coefficients(&p, &filters[p.channel][p.band], (float)audio_state.freq);
-        bool all_bypassed = true;
-        for (int b = 0; b < channel_band_counts[p.channel]; b++) if (!filters[p.channel][b].bypass) { all_bypassed = false; break; }
-        channel_bypassed[p.channel] = all_bypassed;
-    }
-    if (rate_change_pending) { uint32_t r = pending_rate; rate_change_pending = false; fw_perform_rate_change(r); }
-    if (loudness_recompute_pending) { /* :867-875 */
-        loudness_recompute_pending = false;
-        loudness_recompute_table(loudness_ref_spl, loudness_intensity_pct, (float)audio_state.freq);
-        if (loudness_enabled && loudness_active_table) audio_set_volume(audio_state.volume);
-    }
-    if (crossfeed_update_pending) { /* :878-883 */
-        crossfeed_update_pending = false;
-        crossfeed_compute_coefficients(&crossfeed_state, (const CrossfeedConfig *)&crossfeed_config, (float)audio_state.freq);
-        crossfeed_bypassed = !crossfeed_config.enabled;
-    }
-    if (leveller_update_pending) { /* :886-894 */
-        leveller_update_pending = false;
-        leveller_compute_coefficients(&leveller_coeffs, (const LevellerConfig *)&leveller_config, (float)audio_state.freq);
-        if (leveller_reset_pending) { leveller_reset_pending = false; leveller_reset_state(&leveller_state); }
-        leveller_bypassed = !leveller_config.enabled;
-    }
-    if (stream_restart_resync_pending) { stream_restart_resync_pending = false; fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES); }
-    if (preset_load_pending) { /* :926-976 */
-        preset_load_pending = false;
-        uint8_t old_types[NUM_SPDIF_INSTANCES]; memcpy(old_types, output_types, NUM_SPDIF_INSTANCES);
-        fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES);
-        fw_last_preset_status = preset_load(pending_preset_load_slot);
-        /* :957-972: changed slot types go through process_type_switches (:230-424), whose audio-path effect is :279 */
-        if (memcmp(old_types, output_types, NUM_SPDIF_INSTANCES) != 0) fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES);
-    }
-    if (save_params_pending) { save_params_pending = false; fw_prepare_flash_write(); flash_save_params(); }
-    if (preset_save_pending) { preset_save_pending = false; fw_prepare_flash_write(); fw_last_preset_status = preset_save(pending_preset_save_slot); }
-    if (preset_delete_mask) { /* :1010-1052 */
-        uint16_t mask = preset_delete_mask; preset_delete_mask = 0;
-        fw_prepare_flash_write();
-        for (int slot = 0; slot < PRESET_SLOTS; slot++) if (mask & (1u << slot)) preset_delete((uint8_t)slot);
-    }
-    if (factory_reset_pending) { /* :1055-1106 */
-        factory_reset_pending = false;
-        fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES);
-        flash_factory_reset();
-        dsp_recalculate_all_filters((float)audio_state.freq);
-        dsp_update_delay_samples((float)audio_state.freq);
-        loudness_recompute_pending = true; crossfeed_update_pending = true;
-        memset(delay_lines, 0, sizeof(delay_lines));
-        fw_transition_core1();
-    }
-    if (output_type_change_mask) { /* :1110-1121 -> process_type_switches :230-424: the hardware part is not modelled; the audio
-                                    * path sees prepare_pipeline_reset (:279, only when a type really changes, :260-266) and :398 */
-        uint8_t mask = output_type_change_mask; output_type_change_mask = 0;
-        bool any = false;
-        for (int i = 0; i < NUM_SPDIF_INSTANCES; i++)
-            if ((mask & (1u << i)) && pending_output_types[i] <= OUTPUT_TYPE_I2S && pending_output_types[i] != output_types[i]) any = true;
-        if (any) {
-            fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES);
-            for (int i = 0; i < NUM_SPDIF_INSTANCES; i++)
-                if ((mask & (1u << i)) && pending_output_types[i] <= OUTPUT_TYPE_I2S) output_types[i] = pending_output_types[i];
-        }
-    }
-    if (bulk_params_pending) { /* :1126-1162 */
-        bulk_params_pending = false;
-        fw_prepare_pipeline_reset(PRESET_MUTE_SAMPLES);
-        uint16_t occ; uint8_t m, d, la, inc_pins, inc_mv;
-        preset_get_directory(&occ, &m, &d, &la, &inc_pins, &inc_mv);
-        int err = bulk_params_apply((const WireBulkParams *)bulk_param_buf, inc_pins != 0);
-        fw_last_bulk_err = err;
-        if (err == 0) {
-            float rate = (float)audio_state.freq;
-            dsp_recalculate_all_filters(rate);
-            dsp_update_delay_samples(rate);
-            fw_transition_core1();
-        }
-    }
-}
 /* the loop runs until nothing is pending (a serviced flag can raise another, e.g. factory reset -> loudness) */
-static void fw_service_all(void) { for (int i = 0; i < 4; i++) fw_service(); }
+static void fw_service_all(void) { for (int i = 0; i < 4; i++) fw_main_step(); }
 
 /* ------------------------------------------------------------------------------------- */
 /* orc_api.h over the firmware's globals                                                   */
@@ -282,25 +173,7 @@ void orc_set_math_mode(int detmath) { orc_math_mode = detmath; }
 void orc_set_x86_cast_semantics(int on) { (void)on; }      /* compiled casts: always the x86 behaviour */
 
 static int fw_booted;
-static void fw_boot(void) { /* main.c:588-716 core0_init, then the first main-loop pass */
-    usb_sound_card_init();
-    preset_boot_load();
-    dsp_recalculate_all_filters(48000.0f);
-    dsp_update_delay_samples(48000.0f);
-    loudness_recompute_table(loudness_ref_spl, loudness_intensity_pct, 48000.0f);
-    if (loudness_enabled && loudness_active_table) audio_set_volume(audio_state.volume);
-    leveller_compute_coefficients(&leveller_coeffs, (const LevellerConfig *)&leveller_config, 48000.0f);
-    leveller_reset_state(&leveller_state);
-    leveller_bypassed = !leveller_config.enabled;
-    if (matrix_mixer.outputs[NUM_OUTPUT_CHANNELS - 1].enabled) { core1_mode = CORE1_MODE_PDM; pdm_set_enabled(true); }
-    else {
-        bool any = false;
-        for (int i = CORE1_EQ_FIRST_OUTPUT; i <= CORE1_EQ_LAST_OUTPUT; i++) if (matrix_mixer.outputs[i].enabled) { any = true; break; }
-        core1_mode = any ? CORE1_MODE_EQ_WORKER : CORE1_MODE_IDLE;
-        pdm_set_enabled(false);
-    }
-    fw_service_all();
-}
+static void fw_boot(void) { fw_main_start(); fw_service_all(); }      /* main.c:722-736, then a few passes of the loop */
 
 orc_ctx *orc_new(void) {                    /* power-on with an erased flash; one device per library instance */
     unsigned csr = fw_enter();

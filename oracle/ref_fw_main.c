@@ -1,0 +1,68 @@
+/*
+ * ref_fw_main.c — the firmware's main() (firmware/DSPi/main.c: core0_init and the main loop with its deferred-apply dispatcher,
+ * :588-1171) compiled IN PLACE and run as a coroutine.  TEST INFRASTRUCTURE ONLY (oracle/_ref/libref_fw_*.so).
+ *
+ * main() initialises and then loops forever; the loop starts every iteration with watchdog_update().  That call is the yield
+ * point here: fw_main_start() runs main() on its own stack up to the first watchdog_update() (power-on: core0_init, boot preset),
+ * fw_main_step() resumes it for exactly one iteration of the reference's loop — ring drain, flash requests, EQ / rate / loudness /
+ * crossfeed / leveller recomputation, preset load / save / delete, factory reset, output type switches, bulk parameters — all of it
+ * the reference's own code.  Only hardware entry points are stand-ins (ref_fw_stubs.c).
+ *
+ * What the requests return to their caller is not stored by the firmware (its main loop drops the status of bulk_params_apply and
+ * preset_load); the two calls are wrapped so that the oracle API can report them (fw_last_bulk_err, fw_last_preset_status).
+ */
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <math.h>
+#include <ucontext.h>
+#include "pico_stub_all.h"
+#include "config.h"
+#include "dsp_pipeline.h"
+#include "flash_clkdiv.h"
+#include "flash_storage.h"
+#include "pico/audio_i2s_multi.h"
+#include "pdm_generator.h"
+#include "usb_audio.h"
+#include "loudness.h"
+#include "crossfeed.h"
+#include "leveller.h"
+#include "bulk_params.h"
+#include "pico/audio_spdif.h"
+#include "usb_feedback_controller.h"
+#include "pico/audio.h"
+#include "hardware/structs/bus_ctrl.h"
+
+int fw_last_bulk_err, fw_last_preset_status;
+orc_bus_ctrl_hw_t orc_bus_ctrl_hw;
+
+static ucontext_t fw_main_ctx, fw_caller_ctx;
+static int fw_main_running;
+void watchdog_update(void) { if (fw_main_running) swapcontext(&fw_main_ctx, &fw_caller_ctx); }     /* top of every main-loop iteration */
+void watchdog_enable(uint32_t ms, bool pause) { (void)ms; (void)pause; }
+
+#define bulk_params_apply(p, pins) (fw_last_bulk_err = (bulk_params_apply)((p), (pins)))
+#define preset_load(slot) (fw_last_preset_status = (preset_load)(slot))
+#define preset_save(slot) (fw_last_preset_status = (preset_save)(slot))
+#define __asm__                                   /* the two FPSCR accesses (main.c:597-599): the harness sets FTZ|DAZ around every call */
+#define volatile(...) ((void)0)
+#define main fw_main_entry
+#define printf(...) ((void)0)                      /* the firmware logs to its UART */
+#include "main.c"
+#undef main
+#undef printf
+#undef volatile
+#undef __asm__
+
+static char fw_main_stack[1 << 20];
+static void fw_main_tramp(void) { fw_main_entry(); }
+/* power-on: main() up to the top of its loop */
+void fw_main_start(void) {
+    getcontext(&fw_main_ctx);
+    fw_main_ctx.uc_stack.ss_sp = fw_main_stack; fw_main_ctx.uc_stack.ss_size = sizeof fw_main_stack; fw_main_ctx.uc_link = &fw_caller_ctx;
+    makecontext(&fw_main_ctx, fw_main_tramp, 0);
+    fw_main_running = 1;
+    swapcontext(&fw_caller_ctx, &fw_main_ctx);
+}
+/* one iteration of the firmware's main loop */
+void fw_main_step(void) { swapcontext(&fw_caller_ctx, &fw_main_ctx); }

@@ -33,14 +33,12 @@ float orc_hook_log10f(float x) { return orc_math_mode ? dspi_det_log10f(x) : log
 float orc_hook_powf(float a, float b) { return orc_math_mode ? dspi_det_powf(a, b) : powf(a, b); }
 
 /* ---- globals of main.c / usb_feedback_controller.c / usb_descriptors.c that the compiled files name ---- */
-volatile uint32_t feedback_10_14, nominal_feedback_10_14;
-usb_feedback_ctrl_t fb_ctrl;
+/* (main.c's own globals come from main.c now: ref_fw_main.c) */
 void fb_ctrl_init(usb_feedback_ctrl_t *c) { (void)c; }
 void fb_ctrl_reset(usb_feedback_ctrl_t *c, uint32_t v) { (void)c; (void)v; }
 void fb_ctrl_stream_stop(usb_feedback_ctrl_t *c) { (void)c; }
-volatile bool output_type_switch_in_progress;
-volatile uint32_t spdif_overruns, spdif_underruns, pdm_ring_overruns, pdm_ring_underruns, pdm_dma_overruns, pdm_dma_underruns;
-volatile uint32_t usb_audio_packets, usb_audio_alt_set, usb_audio_mounted;
+void fb_ctrl_sof_update(usb_feedback_ctrl_t *c, uint32_t words, uint32_t shift, uint8_t fill) { (void)c; (void)words; (void)shift; (void)fill; }
+uint32_t fb_ctrl_get_10_14(const usb_feedback_ctrl_t *c) { (void)c; return 0; }
 volatile uint32_t usb_error_count, usb_crc_error_count, usb_bitstuff_error_count, usb_rx_overflow_count, usb_rx_timeout_count, usb_data_seq_error_count;
 pio_hw_t orc_pio_hw[3];
 dma_hw_t orc_dma_hw;
@@ -52,7 +50,8 @@ void restore_interrupts(uint32_t s) { (void)s; }
 uint32_t spin_lock_blocking(spin_lock_t *l) { (void)l; return 0; }
 void spin_unlock(spin_lock_t *l, uint32_t s) { (void)l; (void)s; }
 uint32_t time_us_32(void) { return 0; }
-uint64_t time_us_64(void) { return 0; }
+static uint64_t orc_clock_us;
+uint64_t time_us_64(void) { return orc_clock_us += 100; }      /* a clock that moves: the settle wait before flash writes polls it (main.c:560-567) */
 void busy_wait_ms(uint32_t ms) { (void)ms; }
 uint32_t clock_get_hz(uint clk) { (void)clk; return 307200000u; }
 enum vreg_voltage vreg_get_voltage(void) { return VREG_VOLTAGE_1_15; }
@@ -106,6 +105,33 @@ void audio_i2s_mck_set_enabled(bool e) { (void)e; }
 void audio_i2s_mck_setup(PIO pio, uint sm, uint pin) { (void)pio; (void)sm; (void)pin; }
 void audio_i2s_mck_update_frequency(uint32_t f, uint32_t m) { (void)f; (void)m; }
 void audio_i2s_set_enabled(audio_i2s_instance_t *inst, bool e) { (void)inst; (void)e; }
+const audio_format_t *audio_i2s_setup(audio_i2s_instance_t *inst, const audio_format_t *f, const audio_i2s_config_t *c) { (void)inst; (void)c; return f; }
+bool audio_i2s_connect_extra(audio_i2s_instance_t *inst, audio_buffer_pool_t *p, bool b, uint n, audio_connection_t *c) { (void)inst; (void)p; (void)b; (void)n; (void)c; return true; }
+void audio_i2s_teardown(audio_i2s_instance_t *inst) { (void)inst; }
+void audio_i2s_enable_sync(audio_i2s_instance_t *instances[], uint count) { (void)instances; (void)count; }
+void audio_i2s_update_all_frequencies(uint32_t f) { (void)f; }
+void audio_complete_connection(audio_connection_t *c, audio_buffer_pool_t *a, audio_buffer_pool_t *b) { (void)c; (void)a; (void)b; }
+void queue_free_audio_buffer(audio_buffer_pool_t *p, audio_buffer_t *b) { (void)p; (void)b; }
+audio_buffer_t *get_full_audio_buffer(audio_buffer_pool_t *p, bool block) { (void)p; (void)block; return NULL; }      /* nothing is ever queued here */
+
+/* ---- what main.c's bring-up and pipeline resets touch (main.c:588-720, :230-528) ---- */
+static dma_channel_hw_t orc_dma_ch;
+dma_channel_hw_t *dma_channel_hw_addr(uint ch) { (void)ch; return &orc_dma_ch; }
+void dma_irqn_set_channel_enabled(uint irq, uint ch, bool e) { (void)irq; (void)ch; (void)e; }
+void dma_irqn_acknowledge_channel(uint irq, uint ch) { (void)irq; (void)ch; }
+void irq_set_enabled(uint n, bool e) { (void)n; (void)e; }
+bool irq_is_enabled(uint n) { (void)n; return true; }
+int NVIC_GetPriority(int irq) { (void)irq; return 0; }
+void gpio_init(uint g) { (void)g; }
+void gpio_put(uint g, bool v) { (void)g; (void)v; }
+void gpio_xor_mask(uint32_t m) { (void)m; }
+bool set_sys_clock_hz(uint32_t hz, bool required) { (void)hz; (void)required; return true; }
+void set_sys_clock_pll(uint32_t vco, uint pd1, uint pd2) { (void)vco; (void)pd1; (void)pd2; }
+void vreg_set_voltage(enum vreg_voltage v) { (void)v; }
+void pio_sm_claim(PIO pio, uint sm) { (void)pio; (void)sm; }
+void pio_sm_unclaim(PIO pio, uint sm) { (void)pio; (void)sm; }
+void pico_get_unique_board_id_string(char *id, uint len) { if (len) { memset(id, '0', len - 1); id[len - 1] = 0; } }
+void multicore_launch_core1(void (*entry)(void)) { (void)entry; }      /* Core 1 is driven by the harness (ref_fw_core1.c) */
 
 #if !PICO_RP2350
 /* dsp_process_rp2040.S:225-394 — TDF2 cascade, five inlined Q28 multiplies per sample, band-major (same restatement

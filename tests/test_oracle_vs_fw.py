@@ -1,6 +1,6 @@
 """The restated oracle (oracle/orc_chain.c) against the FIRMWARE BUILD of the reference (oracle/ref_fw.c): usb_audio.c's own
-`process_audio_packet`, vendor SET/GET handlers and volume code, flash_storage.c and pdm_generator.c's Core-1 EQ worker,
-compiled in place from /root/reference over a stub pico-sdk.  Same calls into both, every output word / peak / status byte /
+`process_audio_packet`, vendor SET/GET handlers and volume code, flash_storage.c, pdm_generator.c's Core-1 EQ worker and
+main.c's main loop (deferred-apply dispatcher, preset and type-switch handling), compiled in place from /root/reference over a stub pico-sdk.  Same calls into both, every output word / peak / status byte /
 parameter byte compared.  This is what pins the hand restatement of the orchestrator, the control surface and the preset
 code to the reference itself.  Runs where oracle/_ref/libref_fw_*.so exists (needs /root/reference to build); skipped
 elsewhere — the golden fixtures carry the pin to other machines."""
@@ -337,8 +337,8 @@ def test_preset_save_load_delete_through_vendor_requests(flavor):
 @pytest.mark.parametrize("flavor", [1, 0])
 def test_output_type_switches(flavor):
     """REQ_SET_OUTPUT_TYPE / GET (usb_audio.c:2984-3026) and a preset whose slot types differ from the live ones: the handler is
-    the reference's, the deferred switch (main.c:230-424) is restated on both sides (its audio-path effect is the mute,
-    main.c:279; a preset load that changes a type re-arms it with PRESET_MUTE_SAMPLES after the flash hold, main.c:957-972).
+    the reference's and so is the deferred switch (main.c:230-424, run by the firmware build's own main loop); its audio-path
+    effect is the mute (main.c:279; a preset load that changes a type re-arms it with PRESET_MUTE_SAMPLES after the flash hold, main.c:957-972).
     The saved sector carries the types (flash_storage.c:522-529)."""
     R = W.REQ
     fw = Oracle(flavor, ref="fw"); o = Oracle(flavor, x86_casts=True)
