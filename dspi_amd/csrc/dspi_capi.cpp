@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <string>
 #include <map>
+#include <unordered_map>
+#include <type_traits>
 #include <vector>
 #include <thread>
 #include <xmmintrin.h>
@@ -37,6 +39,7 @@ struct dspi_ctx {
     std::vector<uint32_t> image_refs;
     std::vector<int32_t> stream_image;
     bool assignment_dirty = true;
+    bool merge_hint = false;       // a broadcast call ran while several images were live: equal images fold back into one (merge_images)
     // per image, four work lists (dspi_image.h:WgItem): 0 = all streams of the image (state ops; the Q28 chain launch),
     // 1 = lanes whose two streams both belong (float: packed kernel), 2/3 = lanes where only stream 0 / 1 belongs
     std::vector<std::vector<WgItem>> image_items[4];
@@ -121,11 +124,65 @@ int for_targets(dspi_ctx *c, int32_t stream, F f) {
     if (!valid_stream(c, stream)) return fail(c, DSPI_E_INVAL, "stream index out of range");
     if (stream == DSPI_ALL_STREAMS) {
         int rc = 0;
+        if (c->images.size() > 1) c->merge_hint = true;
         for (size_t i = 0; i < c->images.size(); i++)
             if (c->image_refs[i] > 0) { int r = f(*c->images[i]); if (r != 0) rc = r; }
         return rc;
     }
     return f(*writable(c, stream));
+}
+
+// Streams that were given presets of their own and then received the same whole state again (load_bulk / preset / factory reset
+// with DSPI_ALL_STREAMS) hold equal parameter objects: fold them back into one image, so the rows return to the shared-parameter
+// kernels and a commit is one upload again.  Params is trivially copyable and zero-filled before construction, so equal bytes
+// <=> equal parameters, pending state operations included; unequal padding could only keep two images apart, never merge them.
+static_assert(std::is_trivially_copyable<Params>::value, "merge_images compares parameter objects as bytes");
+void merge_images(dspi_ctx *c) {
+    c->merge_hint = false;
+    const size_t ni = c->images.size();
+    std::vector<size_t> live;
+    for (size_t i = 0; i < ni; i++) if (c->image_refs[i] > 0) live.push_back(i);
+    if (ni < 2) return;
+    for (size_t i : live) {
+        Params &p = *c->images[i];
+        p.dirty = true;                                            // everything is uploaded again below; the flag is part of the bytes
+        if (p.ops.reset_all_eq) memset(p.ops.reset_band, 0, sizeof p.ops.reset_band);      // the wipe covers every band (state_ops_kernel): which single bands a stream's history also marked does not matter
+    }
+    std::vector<uint64_t> h(ni, 0);
+    auto hash = [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; k++) {
+            const unsigned char *b = reinterpret_cast<const unsigned char *>(c->images[live[k]].get());
+            uint64_t x = 0xcbf29ce484222325ull;
+            for (size_t j = 0; j + 8 <= sizeof(Params); j += 8) { uint64_t w; memcpy(&w, b + j, 8); x = (x ^ w) * 0x100000001b3ull; x ^= x >> 29; }
+            h[live[k]] = x;
+        }
+    };
+    const size_t n = live.size();
+    const size_t nt = n >= 512 ? std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(32, n / 128)) : 1;
+    if (nt > 1) {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; t++) th.emplace_back(hash, n * t / nt, n * (t + 1) / nt);
+        for (auto &x : th) x.join();
+    } else hash(0, n);
+    std::unordered_map<uint64_t, std::vector<size_t>> seen;     // hash -> surviving images (old indices)
+    std::vector<int32_t> remap(ni, -1);
+    std::vector<size_t> keep;
+    for (size_t i : live) {
+        auto &cands = seen[h[i]];
+        int32_t to = -1;
+        for (size_t k : cands) if (memcmp(c->images[k].get(), c->images[i].get(), sizeof(Params)) == 0) { to = remap[k]; break; }
+        if (to < 0) { to = (int32_t)keep.size(); keep.push_back(i); cands.push_back(i); }
+        remap[i] = to;
+    }
+    if (keep.size() == ni) return;                                // nothing equal, nothing dead
+    std::vector<std::unique_ptr<Params>> images;
+    for (size_t i : keep) images.push_back(std::move(c->images[i]));
+    c->images = std::move(images);
+    c->image_refs.assign(keep.size(), 0);
+    for (auto &si : c->stream_image) { si = remap[(size_t)si]; c->image_refs[(size_t)si]++; }
+    // per-image caches describe the old numbering: drop them, every image goes up again
+    c->image_flags.clear(); c->image_sig.clear(); c->image_bands.clear(); c->image_touched.clear();
+    c->assignment_dirty = true; c->launch_dirty = true;
 }
 
 const Params &readable(const dspi_ctx *c, int32_t stream) {
@@ -311,6 +368,7 @@ bool ops_pending(const StateOps &o) {
 
 // upload dirty images and run pending state mutations; everything is ordered on c->hs
 int commit_params(dspi_ctx *c) {
+    if (c->merge_hint) merge_images(c);
     if (c->assignment_dirty) { int rc = rebuild_assignment(c); if (rc) return rc; }
     const size_t ni = c->images.size();
     bool any_dirty = false;
@@ -610,6 +668,12 @@ int dspi_debug_launch_plan(dspi_ctx *c, uint32_t *counts, size_t n_counts) {
     for (int k = 0; k < 5; k++) counts[k] = (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size());
     if (c->flavor) counts[0] = 0;      // (list 0 of a float context is bookkeeping for the state mutations, never launched)
     return 5;
+}
+
+int dspi_debug_image_count(dspi_ctx *c) {
+    if (!c) return DSPI_E_INVAL;
+    if (c->merge_hint) merge_images(c);
+    return (int)c->images.size();
 }
 
 int dspi_debug_eq_taps(dspi_ctx *c, int32_t stream, int channel, const float *x, uint32_t n, float *taps, float *other) {

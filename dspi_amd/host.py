@@ -176,6 +176,10 @@ class Dspi:
         self._ck(min(self.L.dspi_debug_launch_plan(self.h, c, 5), 0), "debug_launch_plan")
         return dict(zip(("q28_shared", "packed_shared", "one_stream_per_lane_images", "packed_per_lane_values_and_bands", "packed_per_lane_values"), list(c)))
 
+    def image_count(self) -> int:
+        """dspi_debug_image_count: distinct parameter objects held (equal ones are folded after broadcast calls)."""
+        return self._ck(self.L.dspi_debug_image_count(self.h), "debug_image_count")
+
     def eq_taps(self, x: np.ndarray, channel: int, stream: int = 0):
         """dspi_debug_eq_taps: (taps [11][n], other [10][n]) of one EQ channel on the GPU, see include/dspi.h."""
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -43,7 +43,7 @@ extern "C" {
 
 #define DSPI_ABI_VERSION 4   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
                               * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1,
-                              * dspi_debug_launch_plan (additions only) */
+                              * dspi_debug_launch_plan, dspi_debug_image_count (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -215,6 +215,10 @@ int dspi_debug_image(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
  * incl. band coefficients, packed float with per-lane values and shared band coefficients}.  Tests use it to prove that a scenario
  * ran on the path it was written for.  Returns 5 or a negative DSPI_E_*. */
 int dspi_debug_launch_plan(dspi_ctx *ctx, uint32_t *counts, size_t n_counts);
+/* Number of distinct parameter objects the context holds (streams share one until a per-stream call separates them; streams that
+ * received the same whole state again through broadcast calls are folded back, here or at the next dspi_process).  Works on
+ * host-only contexts.  Returns the count or a negative DSPI_E_*. */
+int dspi_debug_image_count(dspi_ctx *ctx);
 
 /* Per-band taps of one EQ channel (float flavour; the parity procedure of SURVEY.md section 8d).  x[n] is run through the ten bands
  * of `channel` (0-1 master, 2.. outputs) of `stream`'s current parameters from zero state, band-major like the firmware's block loop

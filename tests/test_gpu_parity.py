@@ -329,6 +329,28 @@ def test_every_stream_its_own_preset(flavor, fs, B, depth, S):
             rp, rs, rk, _ = o[s_].process(data[s_], blocks, B, depth)
             assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (c, s_)
             assert o[s_].status() == d.status(s_)
+    # the same whole state for everybody again (factory reset, then one blob, broadcast): equal parameter objects fold back into one
+    # image, the rows return to the shared-parameter kernels — with the preset mutes, state resets and the delay lines of each
+    # stream's own history
+    plan = d.launch_plan()
+    assert plan["packed_shared"] == 0 and plan["q28_shared" if not flavor else "one_stream_per_lane_images"] > 0, plan
+    blob2 = WL.full_chain_blob(flavor); blob2["preamp"]["preamp_db"][0] = -4.5
+    assert d.image_count() == S
+    d.factory_defaults(); assert d.load_bulk(blob2) == 0
+    assert d.image_count() == 1
+    for x in o:
+        x.factory_defaults(); assert x.load_bulk(blob2) == 0
+    chunk = np.ascontiguousarray(pcm[:, :blocks * B])
+    data = chunk if depth == 16 else WL.pcm16_to_pcm24_bytes(chunk)
+    pairs, sub, peaks = d.process_host(data, blocks, B, depth)
+    plan = d.launch_plan()
+    rows = (S + (127 if flavor else 63)) // (128 if flavor else 64)
+    if flavor: assert plan["packed_shared"] == rows and plan["packed_per_lane_values_and_bands"] == plan["packed_per_lane_values"] == 0 and plan["one_stream_per_lane_images"] == S % 2, plan
+    else: assert plan["q28_shared"] == rows, plan
+    for s_ in range(S):
+        rp, rs, rk, _ = o[s_].process(data[s_], blocks, B, depth)
+        assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), ("folded", s_)
+        assert o[s_].status() == d.status(s_)
     d.close()
 
 

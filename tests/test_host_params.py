@@ -208,6 +208,39 @@ def test_copy_on_write_images(product_lib):
     assert struct.unpack("<f", d.vendor_get(W.REQ["GET_PREAMP"], 0, stream=3))[0] == 0.0
 
 
+@pytest.mark.parametrize("flavor", [1, 0])
+def test_equal_images_fold_back_after_broadcast_calls(product_lib, flavor):
+    """Streams that were separated by per-stream calls and then receive the same whole state again (broadcast factory reset + blob,
+    or a broadcast request that removes the only difference) share one parameter object again; streams whose parameters — or
+    whose pending state operations — still differ stay apart, and every stream still answers with its own state."""
+    S = 300
+    d = Dspi(flavor, S, device=None)
+    blob = WL.full_chain_blob(flavor)
+    d.set_rate(48000); d.set_volume(-9 * 256); assert d.load_bulk(blob) == 0
+    assert d.image_count() == 1
+    R = W.REQ
+    rng = np.random.default_rng(4)
+    for s_ in range(S):
+        d.vendor_set(R["SET_PREAMP"], 0, struct.pack("<f", -15.0 + 0.1 * s_), stream=s_)
+        if s_ % 3 == 0: d.vendor_set(R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", int(rng.integers(0, 7)), int(rng.integers(0, 10)), W.FILTER_PEAKING, 0, 900.0, 1.1, 3.0), stream=s_)
+        if s_ % 5 == 1: d.vendor_set(R["SET_LEVELLER_ENABLE"], 0, b"\x00", stream=s_)
+        if s_ % 7 == 2: d.set_mute(True, stream=s_)
+        if s_ % 11 == 3: d.set_volume(-256 * s_ % 40, stream=s_)
+    assert d.image_count() == S
+    d.vendor_set(R["SET_PREAMP"], 0, struct.pack("<f", -2.0))                 # ALL: removes one difference; streams 4, 8, 10 ... differ in nothing else
+    plain = [s_ for s_ in range(S) if s_ % 3 and s_ % 5 != 1 and s_ % 7 != 2 and s_ % 11 != 3]
+    distinct = {(d.collect_bulk(s_), s_ % 7 == 2, (-256 * s_ % 40) if s_ % 11 == 3 else None) for s_ in range(S)}
+    assert d.image_count() == len(distinct) and 1 < len(distinct) < S - len(plain) + 2
+    assert len({d.collect_bulk(s_) for s_ in plain}) == 1 and d.collect_bulk(plain[0]) != d.collect_bulk(0)
+    d.set_mute(False); d.set_volume(-9 * 256)
+    d.factory_defaults(); assert d.load_bulk(blob) == 0
+    assert d.image_count() == 1
+    ref = Dspi(flavor, 1, device=None); ref.set_rate(48000); ref.set_volume(-9 * 256); ref.load_bulk(blob); ref.factory_defaults(); ref.load_bulk(blob)
+    assert all(d.collect_bulk(s_) == ref.collect_bulk(0) for s_ in (0, 1, 77, S - 1))
+    d.vendor_set(R["SET_PREAMP"], 0, struct.pack("<f", -6.0), stream=77)       # and apart again
+    assert d.image_count() == 2 and d.collect_bulk(77) != d.collect_bulk(76)
+
+
 def test_process_without_device_fails_loudly(product_lib):
     d = Dspi(1, 4, device=None)
     with pytest.raises(DspiError) as e:
