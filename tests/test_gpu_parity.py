@@ -333,7 +333,7 @@ def test_every_stream_its_own_preset(flavor, fs, B, depth, S):
     # image, the rows return to the shared-parameter kernels — with the preset mutes, state resets and the delay lines of each
     # stream's own history
     plan = d.launch_plan()
-    assert plan["packed_shared"] == 0 and plan["q28_shared" if not flavor else "one_stream_per_lane_images"] > 0, plan
+    assert plan["packed_shared"] == 0 and plan["q28_shared"] == 0 and plan["one_stream_per_lane_images"] > 0, plan
     blob2 = WL.full_chain_blob(flavor); blob2["preamp"]["preamp_db"][0] = -4.5
     assert d.image_count() == S
     d.factory_defaults(); assert d.load_bulk(blob2) == 0
