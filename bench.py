@@ -406,7 +406,11 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
                                                                          "true" if w.get("perstream") else "false", "true" if w.get("perstream") == "eq" else "false")
         if CH == 2: kname = kname.replace("<false, true", "<false, false")
     else:
-        kname = "chain_kernel<0, false, false, false>"
+        # wave layout by launch size (dspi_kernels.hip chain_kernel NW): seven waves up to one 64-stream workgroup per CU, four beyond
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        forced = os.environ.get("DSPI_Q28_WAVES")
+        nw = int(forced) if forced in ("4", "7") else (7 if (S + 63) // 64 <= cus else 4)
+        kname = "chain_kernel<0, false, false, false, %d>" % nw
     roofline = roof(primary)
     roofline["kernel"] = kname
     for m in also:

@@ -1145,8 +1145,12 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const S
 // the one-stream-per-lane kernel (Q28 flavour; float flavour: lanes whose two streams differ in image)
 // ==========================================================================================
 // PL (Q28 only; the float instantiation is always per-lane): per-lane parameter images for rows with several presets
-template <int FLAVOR, bool TAIL, bool PL = false, bool FMA = false>
-__global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
+// NW (Q28 only): waves per workgroup.  4: the roles below, two workgroups per CU — the layout for launches that fill the chip.
+// 7: one output per wave and the right channel's pass 1 on a wave of its own (16 / 12 / 10 x 5 band visits per chunk instead of
+// 16 / 22 / 22 / 24), one workgroup per CU — for launches of at most one workgroup per CU (BASELINE config 5: 16 384 streams = 256
+// workgroups), where four waves leave every SIMD with ONE wave and nothing to hide its dependent-issue latency behind.
+template <int FLAVOR, bool TAIL, bool PL = false, bool FMA = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void chain_kernel(KArgs a) {
     constexpr StateMap sm = make_state_map(FLAVOR);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     float *lds_state = reinterpret_cast<float *>(lds);                      // [lds_slots][64]
@@ -1174,7 +1178,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     const DevImage *img_l = a.img + ((FLAVOR || PL) ? a.stream_image[stream] : 0u);   // float / Q28 PL: this lane's own image (vector loads)
 
     uint32_t *gs = a.state + (size_t)wg * sm.n_slots * ROW + col;
-    for (int s = wave; s < sm.lds_slots; s += 4) lds[s * kLanes + lane] = gs[(size_t)s * ROW];
+    for (int s = wave; s < sm.lds_slots; s += NW) lds[s * kLanes + lane] = gs[(size_t)s * ROW];
     __syncthreads();
 
     Geo g;
@@ -1195,7 +1199,29 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     // SIMD then carries roles r and 3 - r (40 / 44 / 44 / 40) instead of the same role twice (32 / 44 / 44 / 48).  Any
     // assignment is correct; should the placement ever not give four different roles, the wave index is used.
     int role = wave;
-    if (FLAVOR == 0) {
+    if (FLAVOR == 0 && NW == 7) {
+        // seven waves: three SIMDs carry two, one carries one (when the placement is the usual round robin) — the lone wave takes
+        // role 0 (16), the others the right channel's pass 1 (role 6, 12) and the five outputs (roles 1..5, 10 each) in wave order
+        uint32_t *role_tab = reinterpret_cast<uint32_t *>(q_envr + 2 * kLanes);     // [7]
+        const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (5 << 11));
+        if (lane == (uint32_t)__builtin_ctzll(item.mask)) role_tab[wave] = (hw >> 4) & 3u;
+        __syncthreads();
+        uint32_t tab[7];
+#pragma unroll
+        for (int w = 0; w < 7; ++w) tab[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)role_tab[w]) & 3u;
+        int lone = 0;
+#pragma unroll
+        for (int w = 6; w >= 0; --w) {
+            int same = 0;
+#pragma unroll
+            for (int v = 0; v < 7; ++v) same += (tab[v] == tab[w]);
+            if (same == 1) lone = w;
+        }
+        int rank = 0;
+#pragma unroll
+        for (int w = 0; w < 7; ++w) if (w < wave && w != lone) ++rank;
+        role = __builtin_amdgcn_readfirstlane(wave == lone ? 0 : (rank == 0 ? 6 : rank));
+    } else if (FLAVOR == 0) {
         uint32_t *role_tab = reinterpret_cast<uint32_t *>(q_envr + 2 * kLanes);     // [4]
         const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (5 << 11));      // hwreg(HW_REG_HW_ID, 0, 6): wave slot [3:0], SIMD [5:4]
         const uint32_t simd = (hw >> 4) & 3u;
@@ -1274,14 +1300,14 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
         int32_t *qpk = reinterpret_cast<int32_t *>(lds_pk);
         const int32_t *qxch = reinterpret_cast<const int32_t *>(xch);
         // 5 outputs over waves 1..3: pair 0, pair 1, sub; wave 3 also runs pass 1 of the right channel (role 3 above)
-        const int o_first = (role - 1) * 2;
-        const int o_count = (role <= sm.n_pairs) ? 2 : 1;
-        const bool right = (role == 3);
+        const int o_first = NW == 7 ? role - 1 : (role - 1) * 2;
+        const int o_count = NW == 7 ? (role <= sm.n_out ? 1 : 0) : ((role <= sm.n_pairs) ? 2 : 1);
+        const bool right = NW == 7 ? (role == 6) : (role == 3);
         OutQ28 s;
         s.widx = gs[sm.widx * ROW];
         s.loading = gs[(sm.mute + 0) * ROW]; s.counter = gs[(sm.mute + 1) * ROW]; s.smooth = as_f(gs[(sm.mute + 2) * ROW]);
         s.vmm = 0;
-        s.clip = gs[(sm.clip + role) * ROW];
+        s.clip = NW == 7 ? 0u : gs[(sm.clip + role) * ROW];      // seven waves share the four sticky words: new bits are ORed in at the end
         int32_t env_r = right ? (int32_t)gs[(sm.lev + 1) * ROW] : 0;
         uint32_t rp1 = gs[sm.ring_pos * ROW] & (kRingLen - 1);
         uint32_t kq = 0, cq = 0, k1 = 0, c1 = 0;
@@ -1298,7 +1324,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             } else if (right) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last chunks' ring rows (master_p1_q28 drains one step late)
             }
-            if (st >= g.lag + 1) {
+            if (o_count && st >= g.lag + 1) {
                 const uint32_t q = st - g.lag - 1;
                 if (TAIL && (cq + 1) * T > g.B) {
                     if (PL) output_item_q28<true>(a, img_l, sm, g, s, qstate, qpk, qxch, wg, lane, stream, o_first, o_count, kq, cq, q);
@@ -1316,7 +1342,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
             gs[(sm.mute + 0) * ROW] = s.loading; gs[(sm.mute + 1) * ROW] = s.counter; gs[(sm.mute + 2) * ROW] = as_u(s.smooth);
         }
         if (right) gs[(sm.lev + 1) * ROW] = (uint32_t)env_r;
-        gs[(sm.clip + role) * ROW] = s.clip;
+        if (NW == 7) { if (s.clip) atomicOr(gs + (size_t)(sm.clip + 1 + (role % 3)) * ROW, s.clip); }
+        else gs[(sm.clip + role) * ROW] = s.clip;
     } else if (wave == 0) {
         MasterF32 m;
         m.lpL = as_f(gs[(sm.xfeed + 0) * ROW]); m.lpR = as_f(gs[(sm.xfeed + 1) * ROW]);
@@ -1396,7 +1423,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(KArgs a) {
     }
     __syncthreads();
     if (active)
-        for (int s = wave; s < sm.lds_slots; s += 4) gs[(size_t)s * ROW] = lds[s * kLanes + lane];
+        for (int s = wave; s < sm.lds_slots; s += NW) gs[(size_t)s * ROW] = lds[s * kLanes + lane];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1470,8 +1497,35 @@ size_t chain_lds_bytes(int flavor, int packed) {
 
 constexpr int kMaxDevices = 65;      // slot 64: any device index beyond (attribute set on every launch)
 
+// Q28 launches of at most one workgroup per CU take the seven-wave layout (chain_kernel: NW)
+template <bool PL>
+static hipError_t launch_chain_q28_7(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    const size_t lds = chain_lds_bytes(0, 0);
+    static bool attr_set[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
+    if (!attr_set[dev] || dev == kMaxDevices - 1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<0, false, PL, false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel<0, true, PL, false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    if (args.block_len % T) hipLaunchKernelGGL((chain_kernel<0, true, PL, false, 7>), dim3(n_items), dim3(64 * 7), lds, stream, args);
+    else hipLaunchKernelGGL((chain_kernel<0, false, PL, false, 7>), dim3(n_items), dim3(64 * 7), lds, stream, args);
+    return hipGetLastError();
+}
+static uint32_t q28_seven_wave_limit() {      // work items up to which the seven-wave layout is used: one per CU; DSPI_Q28_WAVES=4 / 7 forces one layout (tests, development)
+    if (const char *e = getenv("DSPI_Q28_WAVES")) { const int w = atoi(e); if (w == 7) return 0xffffffffu; if (w == 4) return 0u; }
+    static int cus[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices - 1) return 256u;
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
+    return (uint32_t)cus[dev];
+}
+
 template <int FLAVOR, bool PL, bool FMA = false>
 static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    if constexpr (FLAVOR == 0) { if (n_items <= q28_seven_wave_limit()) return launch_chain_q28_7<PL>(args, n_items, stream); }
     const size_t lds = chain_lds_bytes(FLAVOR, 0);
     // the dynamic-LDS limit is a per-device function attribute: remember it per device (contexts on several GPUs may
     // share one process; a context is single-threaded)

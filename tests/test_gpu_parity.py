@@ -73,6 +73,17 @@ def test_full_chain(flavor, fs, B, depth):
     compare(flavor, fs, B, 24, 85, WL.full_chain_blob(flavor), depth=depth)
 
 
+@pytest.mark.parametrize("waves", ["4", "7", None])
+def test_q28_wave_layouts(waves, monkeypatch):
+    """The Q28 kernel's two wave layouts (four waves: two outputs per wave; seven: one output per wave, for launches of at most one
+    workgroup per CU) and the size rule that picks between them: the same words, peaks and sticky clip bits (the seven-wave
+    layout ORs its bits into shared words) — full chain, ragged packets, a clipping stream class, two calls."""
+    if waves is None: monkeypatch.delenv("DSPI_Q28_WAVES", raising=False)
+    else: monkeypatch.setenv("DSPI_Q28_WAVES", waves)
+    compare(0, 48000, 48, 24, 150, WL.full_chain_blob(0), calls=2)
+    compare(0, 44100, 45, 20, 70, WL.full_chain_blob(0), depth=24, calls=2, first_stream=15)
+
+
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 @pytest.mark.parametrize("lev", [1, 0])
 def test_ragged_packets_delay_edges(flavor, lev):
