@@ -1489,14 +1489,25 @@ __global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
+// Parallel build (Makefile): this file is compiled once per DSPI_PART.  Part 0 holds everything except the packed float kernels;
+// parts 1..6 hold one (FMA, PV, PVB) family of chain_kernel_pk each (16 kernels: TAIL x LEV x PCM24 x TILED).  Every part is its own
+// code object inside the shared library.  Without DSPI_PART the file is one translation unit (the timing build).
+#if !defined(DSPI_PART) || DSPI_PART == 0
+#define DSPI_PART_MAIN 1
+#endif
+
+#ifdef DSPI_PART_MAIN
 size_t chain_lds_bytes(int flavor, int packed) {
     const StateMap sm = make_state_map(flavor);
     // Q28 one-stream kernel: + queued gain decisions, the posted right-channel envelope and the role table (kQ28Mail + 2 + 1 rows)
     return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox + 2 : (flavor ? 0 : 7))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);      // packed: + role table (16 B) and the posted left envelope (2 rows)
 }
 
+#endif
+
 constexpr int kMaxDevices = 65;      // slot 64: any device index beyond (attribute set on every launch)
 
+#ifdef DSPI_PART_MAIN
 // Q28 launches of at most one workgroup per CU take the seven-wave layout (chain_kernel: NW)
 template <bool PL>
 static hipError_t launch_chain_q28_7(const KArgs &args, uint32_t n_items, hipStream_t stream) {
@@ -1543,6 +1554,8 @@ static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_
     return hipGetLastError();
 }
 
+#endif  // DSPI_PART_MAIN
+
 template <bool TAIL, bool LEV, bool PCM24, bool TILED, bool FMA, bool PV, bool PVB>
 static hipError_t launch_chain_pk_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     const size_t lds = chain_lds_bytes(1, 1);
@@ -1572,6 +1585,36 @@ static hipError_t launch_chain_pk(const KArgs &args, bool leveller_on, uint32_t 
     return leveller_on ? launch_chain_pk_2<false, true, FMA, PV, PVB>(args, n_items, stream) : launch_chain_pk_2<false, false, FMA, PV, PVB>(args, n_items, stream);
 }
 
+
+// one exported launcher per kernel family: family = (FMA ? 3 : 0) + (PVB ? 2 : PV ? 1 : 0)
+hipError_t launch_chain_pk_f0(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream);
+hipError_t launch_chain_pk_f1(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream);
+hipError_t launch_chain_pk_f2(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream);
+hipError_t launch_chain_pk_f3(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream);
+hipError_t launch_chain_pk_f4(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream);
+hipError_t launch_chain_pk_f5(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream);
+#define DSPI_PK_FAMILY(N, FMA, PV, PVB) \
+    hipError_t launch_chain_pk_f##N(const KArgs &args, bool leveller_on, uint32_t n_items, hipStream_t stream) { return launch_chain_pk<FMA, PV, PVB>(args, leveller_on, n_items, stream); }
+#if !defined(DSPI_PART) || DSPI_PART == 1
+DSPI_PK_FAMILY(0, false, false, false)
+#endif
+#if !defined(DSPI_PART) || DSPI_PART == 2
+DSPI_PK_FAMILY(1, false, true, false)
+#endif
+#if !defined(DSPI_PART) || DSPI_PART == 3
+DSPI_PK_FAMILY(2, false, true, true)
+#endif
+#if !defined(DSPI_PART) || DSPI_PART == 4
+DSPI_PK_FAMILY(3, true, false, false)
+#endif
+#if !defined(DSPI_PART) || DSPI_PART == 5
+DSPI_PK_FAMILY(4, true, true, false)
+#endif
+#if !defined(DSPI_PART) || DSPI_PART == 6
+DSPI_PK_FAMILY(5, true, true, true)
+#endif
+
+#ifdef DSPI_PART_MAIN
 // ---- value tiles of the per-lane-value rows (dspi_image.h): one thread per (row, word, column) ----
 __global__ void pv_clear_kernel(const uint32_t *rows, float *vals, uint32_t all_differ) {
     uint32_t *mask = reinterpret_cast<uint32_t *>(vals + (size_t)rows[blockIdx.x] * kPvTileFloats + kPvMaskWord);
@@ -1631,9 +1674,9 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
     if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
     // float: the context's contract (DSPI_FLOAT_CONTRACT_FMA) picks the kernel family
     if (packed != 1 && packed != 3 && packed != 4) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
-    if (packed == 3) return args.fma ? launch_chain_pk<true, true, true>(args, leveller_on, n_items, stream) : launch_chain_pk<false, true, true>(args, leveller_on, n_items, stream);
-    if (packed == 4) return args.fma ? launch_chain_pk<true, true, false>(args, leveller_on, n_items, stream) : launch_chain_pk<false, true, false>(args, leveller_on, n_items, stream);
-    return args.fma ? launch_chain_pk<true, false, false>(args, leveller_on, n_items, stream) : launch_chain_pk<false, false, false>(args, leveller_on, n_items, stream);
+    if (packed == 3) return args.fma ? launch_chain_pk_f5(args, leveller_on, n_items, stream) : launch_chain_pk_f2(args, leveller_on, n_items, stream);
+    if (packed == 4) return args.fma ? launch_chain_pk_f4(args, leveller_on, n_items, stream) : launch_chain_pk_f1(args, leveller_on, n_items, stream);
+    return args.fma ? launch_chain_pk_f3(args, leveller_on, n_items, stream) : launch_chain_pk_f0(args, leveller_on, n_items, stream);
 }
 
 // ---- debug: per-band taps of one float EQ channel (include/dspi.h dspi_debug_eq_taps) ----
@@ -1696,5 +1739,7 @@ extern "C" int dspi_debug_wave_timing(unsigned long long *out84, int reset) {
     return 0;
 }
 #endif
+
+#endif  // DSPI_PART_MAIN
 
 }  // namespace dspi
