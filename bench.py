@@ -277,9 +277,12 @@ def main():
     torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # DSPI_BENCH_FORCE_DIST=1: take the process-group path at world size 1 too — communicator creation, the barriers around the timed
+    # region and the device-tensor all_reduce(MAX) then run over RCCL on a one-GPU box (tests/test_gpu_dist.py)
+    if world > 1 or os.environ.get("DSPI_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1: os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":      # RCCL over xGMI
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
         else:
@@ -289,6 +292,9 @@ def main():
         out = bench_consumer(args, torch, dev, rank, world, dist, backend)
     else:
         out = bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_range)
+    if dist and out is not None:      # (ranks other than 0 return None)
+        out["dist"] = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world_size": world,
+                       "collective": "all_reduce(MAX) of the elapsed time, 8 bytes, after the timed region"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist: dist.destroy_process_group()

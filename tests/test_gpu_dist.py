@@ -88,3 +88,19 @@ def test_bench_self_spawn_two_ranks(scaling):
     assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and rec["value"] > 0 and rec["steps"] == 2
     per_rank = 2048 if scaling == "weak" else 1024
     assert rec["config"]["streams_per_gpu"] == per_rank, rec["config"]
+
+
+def test_bench_rccl_branch_world_size_one():
+    """The RCCL branch of bench.py on real hardware: DSPI_BENCH_FORCE_DIST=1 makes a one-rank run create the nccl (= RCCL) process
+    group bound to the context's device, pass the barriers around the timed region and all-reduce the elapsed time on a device tensor.
+    (N > 1 over xGMI is the driver's 8-GPU run; this proves communicator creation and the collective where one GPU exists.)"""
+    env = dict(os.environ, DSPI_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSPI_BENCH_BACKEND", "MASTER_PORT"): env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--streams", "2048",
+                        "--no-cpu-baseline", "--no-variants"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["dist"]["world_size"] == 1 and rec["dist"]["backend"].startswith("rccl"), rec.get("dist")

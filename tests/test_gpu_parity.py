@@ -406,13 +406,14 @@ def test_golden_fixtures_on_gpu(path):
     d.close()
 
 
-def test_full_size_properties():
-    """BASELINE config 3 at full size (65 536 streams): (i) streams are independent and placement-invariant — a stream
-    gives the same words whatever its lane/workgroup; (ii) identical inputs give identical outputs in every lane;
-    (iii) a sample of streams is bit-exact against the oracle; (iv) linear-phase sanity: digital silence in -> silence out."""
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+def test_full_size_properties(flavor):
+    """BASELINE config 3 at full size (65 536 streams), stream-major words, both float contracts: (i) streams are independent and
+    placement-invariant — a stream gives the same words whatever its lane/workgroup; (ii) identical inputs give identical outputs in
+    every lane; (iii) a sample of streams is bit-exact against the oracle; (iv) linear-phase sanity: digital silence in -> silence out."""
     import torch
     fs, B, blocks, S = 96000, 96, 4, 65536
-    d = Dspi(1, S, device=0)
+    d = Dspi(flavor, S, device=0)
     d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(WL.full_chain_blob(1)) == 0
     base = WL.synth_pcm16(128, B * blocks, fs)
     idx = np.arange(S) % 128
@@ -428,19 +429,23 @@ def test_full_size_properties():
     assert torch.equal(pairs[5 + 128 * 37], pairs[5]) and torch.equal(sub[5 + 128 * 400], sub[5])
     assert int(pairs[7777].abs().max()) == 0 and int(sub[7777].abs().max()) == 0
     for s in (0, 63, 64, 4095, 65471):
-        (rp, rs, _, _), _ = oracle_run(1, fs, -20 * 256, WL.full_chain_blob(1), base[idx[s]], blocks, B, 16)
+        (rp, rs, _, _), _ = oracle_run(flavor, fs, -20 * 256, WL.full_chain_blob(1), base[idx[s]], blocks, B, 16)
         assert np.array_equal(rp, pairs[s].cpu().numpy()) and np.array_equal(rs, sub[s].cpu().numpy())
     d.close()
 
 
-@pytest.mark.parametrize("flavor,fs,B", [(1, 96000, 96), (1, 44100, 45), (1, 48000, 16), (0, 48000, 48), (0, 44100, 44), (0, 48000, 16), (0, 48000, 20), (0, 48000, 7)])
-def test_full_size_all_tiles_agree(flavor, fs, B):
+@pytest.mark.parametrize("flavor,fs,B,S", [(1, 96000, 96, 65536), (1, 44100, 45, 65536), (1, 48000, 16, 65536), (W.F32_FMA, 96000, 96, 65536), (W.F32_FMA, 44100, 45, 65536),
+                                          (0, 48000, 48, 65536), (0, 44100, 44, 65536), (0, 48000, 16, 65536), (0, 48000, 20, 65536), (0, 48000, 7, 65536),
+                                          (0, 48000, 48, 16384), (0, 44100, 45, 16384)])
+def test_full_size_all_tiles_agree(flavor, fs, B, S, monkeypatch):
     """Race detector at full size on the path the bench times (tiled words, device buffers, several launches): every
     tile gets the same streams of input, so every tile must produce the words of tile 0 — which is checked against the
     oracle on a few streams.  A stale ring row, a lost barrier or a role mix-up in any workgroup shows up here (float:
     512 workgroups of twelve waves; Q28: 1024 workgroups whose two master waves meet in the ring)."""
     import torch
-    blocks, S, calls = (14 if B > 20 else 60), 65536, 3
+    # (Q28 at 16 384 streams = BASELINE config 5's own size: 256 rows, the seven-wave layout on every CU — the size rule must pick it)
+    if S == 16384: monkeypatch.delenv("DSPI_Q28_WAVES", raising=False)
+    blocks, calls = (14 if B > 20 else 60), 3
     n_out, n_ch = (9, 11) if flavor else (5, 7)
     d = Dspi(flavor, S, device=0)
     d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(WL.full_chain_blob(flavor)) == 0
@@ -467,6 +472,87 @@ def test_full_size_all_tiles_agree(flavor, fs, B):
         got = np.stack([np.stack([p0[2 * p, :, s], p0[2 * p + 1, :, s]], axis=-1) for p in range((n_out - 1) // 2)])
         assert np.array_equal(last, got) and np.array_equal(rs[(calls - 1) * frames:], s0[:, s])
     d.close()
+
+
+@pytest.mark.parametrize("flavor,fs,B,blocks", [(W.F32_FMA, 96000, 96, 14), (1, 96000, 96, 14), (W.F32_FMA, 44100, 45, 15), (W.F32_FMA, 48000, 48, 50)],
+                         ids=("fma-96k", "canonical-96k", "fma-44k1-ragged", "fma-48k-50pk"))
+def test_full_size_stream_major_groups_agree(flavor, fs, B, blocks):
+    """Race detector on the variant bench.py times by default: firmware float contract, STREAM-MAJOR words (the firmware's
+    [stream][pair][frame][2] buffers, written as whole lines), device buffers, three launches.  Every 128-stream group gets the
+    same input, so every group must produce group 0's words, sub words and peaks; group 0 is checked against the oracle."""
+    import torch
+    S, calls, R = 65536, 3, 128
+    d = Dspi(flavor, S, device=0)
+    d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(WL.full_chain_blob(1)) == 0
+    base = WL.synth_pcm16(R, B * blocks * calls, fs)
+    dev = torch.device("cuda", 0)
+    groups, frames = S // R, B * blocks
+    pairs = torch.empty((S, 4, frames, 2), dtype=torch.int32, device=dev); sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
+    peaks = torch.empty((S, blocks, 11), dtype=torch.int16, device=dev)
+    for c in range(calls):
+        part = torch.from_numpy(np.ascontiguousarray(base[:, c * frames:(c + 1) * frames])).to(dev)
+        pcm = part.repeat(groups, 1, 1).contiguous()
+        pairs.fill_(0x55555555); sub.fill_(0x55555555)            # a word nobody wrote shows up
+        torch.cuda.synchronize()
+        d.process_device(pcm.data_ptr(), blocks, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr()); d.sync()
+        pv, sv, kv = pairs.view(groups, R, 4, frames, 2), sub.view(groups, R, frames), peaks.view(groups, R, blocks, 11)
+        assert bool((pv == pv[0:1]).all()), f"launch {c}: a group's pair words differ from group 0"
+        assert bool((sv == sv[0:1]).all()), f"launch {c}: a group's sub words differ from group 0"
+        assert bool((kv == kv[0:1]).all()), f"launch {c}: a group's peaks differ from group 0"
+    p0, s0 = pairs[:R].cpu().numpy(), sub[:R].cpu().numpy()
+    for s in (0, 1, 63, 64, R - 1):
+        (rp, rs, _, _), _ = oracle_run(flavor, fs, -20 * 256, WL.full_chain_blob(1), base[s], blocks * calls, B, 16)
+        assert np.array_equal(rp[:, (calls - 1) * frames:, :], p0[s]) and np.array_equal(rs[(calls - 1) * frames:], s0[s]), s
+    d.close()
+
+
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+def test_flash_dump_boots_device_context(flavor):
+    """SURVEY 8f-4 on the GPU: dspi_load_flash_dump on a DEVICE context (v2 directory, v1 directory, corrupt selected slot -> factory
+    defaults, legacy "DSP1" sector -> migrated slot 0; flash_storage.c:1047-1105, :370-417, :997-1045), then audio.  Every word from
+    the first packet on against the restatement opened with the same dump (same preset-load mute), and, where oracle/_ref holds the
+    firmware build, the packets after the mutes have run out against the reference's own flash code BOOTED from that dump."""
+    from test_flash_dump import make_slots
+    fl = int(flavor)
+    slots = make_slots(fl); occ = sum(1 << n for n in slots)
+    D, F = W.flash_dump, W.flash_directory
+    bad = dict(slots); b = bytearray(bad[4]); b[100] ^= 0x40; bad[4] = bytes(b)
+    cases = [(D(F(default_slot=4, last_active_slot=9, slot_occupied=occ, master_volume_db=-17.0), slots), 4),
+             (D(F(version=1, default_slot=9, slot_occupied=occ, master_volume_mode=1, names={9: "Night"}), slots), 9),
+             (D(F(default_slot=4, slot_occupied=occ), bad), 16 + 4),
+             (D(None, {}, W.legacy_sector_from_slot(slots[4], fl, version=7)), 32)]
+    fs, B, warm, blocks, S = 48000, 48, 120, 20, 70
+    fma = bool(getattr(flavor, "fma", False))
+    # (Q28: the x86 build of the reference casts an out-of-range limiter quotient to INT_MIN where the MCU saturates — DESIGN.md section 5 —
+    #  so the firmware-build leg runs for the float flavour only; tests/test_oracle_vs_fw.py pins the Q28 restatement with x86 casts)
+    have_fw = fl == 1 and orclib.ref_available(fl, "fw", fma)
+    pcm = WL.synth_pcm16(S, B * (warm + blocks), fs)
+    for dump, want in cases:
+        d = Dspi(flavor, S, device=0)
+        assert d.set_rate(fs) == 0
+        d.set_volume(-12 * 256)
+        assert d.load_flash_dump(dump) == want
+        outs = [d.process_host(np.ascontiguousarray(pcm[:, a * B:b_ * B]), b_ - a, B) for a, b_ in ((0, warm), (warm, warm + blocks))]
+        for s in (0, 5, 64, S - 1):
+            o = Oracle(flavor, detmath=True)
+            assert o.set_rate(fs) == 0
+            o.set_volume(-12 * 256)
+            assert o.load_flash_dump(dump) == want
+            rp, rs, rk, _ = o.process(pcm[s], warm + blocks, B)
+            assert np.array_equal(rp, np.concatenate([x[0][s] for x in outs], axis=1)), (want, s)
+            assert np.array_equal(rs, np.concatenate([x[1][s] for x in outs])) and np.array_equal(rk, np.concatenate([x[2][s] for x in outs])), (want, s)
+            assert o.status() == d.status(s)
+            assert o.collect_bulk() == d.collect_bulk(s)
+            if have_fw and s in (0, 64):
+                fw = Oracle(fl, ref="fw", flash=dump, fma=fma)
+                assert fw.set_rate(fs) == 0
+                fw.set_volume(-12 * 256)
+                fw.process(pcm[s][:warm * B], warm, B)                     # boot mute and its trace in the delay lines run out
+                fp, fsub, fk, _ = fw.process(pcm[s][warm * B:], blocks, B)
+                assert np.array_equal(fp, outs[1][0][s]) and np.array_equal(fsub, outs[1][1][s]) and np.array_equal(fk, outs[1][2][s]), ("firmware build", want, s)
+                fw.close()
+            o.close()
+        d.close()
 
 
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
