@@ -53,6 +53,9 @@ struct dspi_ctx {
     bool launch_dirty = true;
     // device
     hipStream_t hs = nullptr;
+    // host-buffer dspi_process: H2D, kernels and D2H of consecutive row chunks overlap on three streams (created on first use)
+    hipStream_t hs_in = nullptr, hs_out = nullptr;
+    std::vector<hipEvent_t> pipe_events;
     uint32_t *d_state = nullptr, *d_dlines = nullptr, *d_ring = nullptr;
     uint32_t *d_xwords = nullptr; size_t d_xwords_cap = 0;      // exchange area of the packed kernel's copy wave (stream-major output)
     DevImage *d_images = nullptr;
@@ -341,6 +344,8 @@ int rebuild_launch_lists(dspi_ctx *c) {
                     }
                 }
             }
+            // by row: a range of rows is then a contiguous run of every list (dspi_process stages host buffers row chunk by row chunk)
+            std::stable_sort(v.begin(), v.end(), [](const WgItem &x, const WgItem &y) { return x.wg < y.wg; });
             c->launch_item_offset[lev][k] = (uint32_t)total;
             total += v.size();
         }
@@ -554,6 +559,9 @@ void dspi_destroy(dspi_ctx *c) {
         for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_xwords, (void *)c->d_vals, (void *)c->d_pv_rows, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_stream_image, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
             if (p) (void)hipFree(p);
+        for (hipEvent_t e : c->pipe_events) (void)hipEventDestroy(e);
+        if (c->hs_in) (void)hipStreamDestroy(c->hs_in);
+        if (c->hs_out) (void)hipStreamDestroy(c->hs_out);
         if (c->hs) (void)hipStreamDestroy(c->hs);
     }
     delete c;
@@ -834,7 +842,6 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         a.pcm = pcm_in; a.pairs = out->pairs; a.sub = out->sub; a.peaks = out->peaks;
     } else {
         if ((rc = ensure(c, c->d_in, c->d_in_cap, in_b))) return rc;
-        HIPCK(c, hipMemcpyAsync(c->d_in, pcm_in, in_b, hipMemcpyHostToDevice, c->hs));
         a.pcm = c->d_in;
         if (out->pairs) { if ((rc = ensure(c, c->d_pairs, c->d_pairs_cap, pairs_b))) return rc; a.pairs = c->d_pairs; }
         if (out->sub) { if ((rc = ensure(c, c->d_sub, c->d_sub_cap, sub_b))) return rc; a.sub = c->d_sub; }
@@ -851,21 +858,96 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     const Launch *ls = c->flavor ? kF32 : kQ28;
     const int nl = c->flavor ? 4 : 2;
     a.vals = c->d_vals;
-    for (int lev = 0; lev < 2; lev++)
-        for (int l = 0; l < nl; l++) {
-            const auto &items = c->launch_items[lev][ls[l].list];
-            if (items.empty()) continue;
-            a.items = c->d_litems + c->launch_item_offset[lev][ls[l].list];
-            hipError_t e = launch_chain(c->flavor, ls[l].packed, lev != 0, a, (uint32_t)items.size(), c->hs);
-            if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
-            if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));
-        }
-    if (!dev) {
-        if (out->pairs) HIPCK(c, hipMemcpyAsync(out->pairs, c->d_pairs, pairs_b, hipMemcpyDeviceToHost, c->hs));
-        if (out->sub) HIPCK(c, hipMemcpyAsync(out->sub, c->d_sub, sub_b, hipMemcpyDeviceToHost, c->hs));
-        if (out->peaks) HIPCK(c, hipMemcpyAsync(out->peaks, c->d_peaks, peaks_b, hipMemcpyDeviceToHost, c->hs));
-        HIPCK(c, hipStreamSynchronize(c->hs));
+    // the chain launches for the rows [r0, r1) (the lists are sorted by row)
+    auto launch_rows = [&](uint32_t r0, uint32_t r1) -> int {
+        for (int lev = 0; lev < 2; lev++)
+            for (int l = 0; l < nl; l++) {
+                const auto &items = c->launch_items[lev][ls[l].list];
+                if (items.empty()) continue;
+                auto by_row = [](const WgItem &it, uint32_t r) { return it.wg < r; };
+                const size_t lo = (size_t)(std::lower_bound(items.begin(), items.end(), r0, by_row) - items.begin());
+                const size_t hi = (size_t)(std::lower_bound(items.begin(), items.end(), r1, by_row) - items.begin());
+                if (hi == lo) continue;
+                a.items = c->d_litems + c->launch_item_offset[lev][ls[l].list] + lo;
+                hipError_t e = launch_chain(c->flavor, ls[l].packed, lev != 0, a, (uint32_t)(hi - lo), c->hs);
+                if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
+                if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));
+            }
+        return 0;
+    };
+    if (dev) return launch_rows(0, c->n_wg);
+
+    // ---- host buffers (the caller of usb_audio.c:1326-1332 is a host feeding packets): staged through device buffers.  The link moves
+    // 4 + 36 bytes per frame, the chain 100 times that, so the call is link-bound; what can be saved is the serialisation: the rows are
+    // cut into chunks and chunk i's D2H runs while chunk i+1 computes and chunk i+2 uploads (three streams, events).  The caller's
+    // buffers are pinned for the duration of the call (hipHostRegister: ~8 ms per GiB) so that the copies are asynchronous DMA; when
+    // that is refused (already registered, read-only mapping ...) the copies still work, just synchronously. ----
+    const uint32_t row = (uint32_t)c->sm.row;
+    const size_t out_b = (out->pairs ? pairs_b : 0) + (out->sub ? sub_b : 0) + (out->peaks ? peaks_b : 0);
+    uint32_t n_chunks = 1;
+    if (out_b + in_b >= (32u << 20) && c->n_wg >= 2) {
+        n_chunks = (uint32_t)std::min<size_t>({(size_t)8, (size_t)c->n_wg, (out_b + in_b) / (16u << 20)});
+        if (n_chunks < 1) n_chunks = 1;
     }
+    const uint32_t rows_per = (c->n_wg + n_chunks - 1) / n_chunks;
+    n_chunks = (c->n_wg + rows_per - 1) / rows_per;
+    struct Pin { void *p; bool on; };
+    Pin pins[4] = {{const_cast<void *>(pcm_in), false}, {out->pairs, false}, {out->sub, false}, {out->peaks, false}};
+    const size_t pin_b[4] = {in_b, pairs_b, sub_b, peaks_b};
+    if (n_chunks > 1)
+        for (int i = 0; i < 4; i++)
+            if (pins[i].p && pin_b[i] >= (1u << 20)) {
+                pins[i].on = hipHostRegister(pins[i].p, pin_b[i], hipHostRegisterDefault) == hipSuccess;
+                if (!pins[i].on) (void)hipGetLastError();
+            }
+    auto unpin = [&]() { for (auto &pn : pins) if (pn.on) { (void)hipHostUnregister(pn.p); pn.on = false; } };
+    if (n_chunks > 1 && !c->hs_in) {
+        if (hipStreamCreateWithFlags(&c->hs_in, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->hs_out, hipStreamNonBlocking) != hipSuccess) {
+            unpin(); return fail(c, DSPI_E_HIP, "stream creation for the host-buffer pipeline failed");
+        }
+    }
+    while (n_chunks > 1 && c->pipe_events.size() < 2 * (size_t)n_chunks) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { unpin(); return fail(c, DSPI_E_HIP, "event creation failed"); }
+        c->pipe_events.push_back(e);
+    }
+    const size_t bpf = bit_depth == 24 ? 6 : 4;
+    auto fail_hip = [&](hipError_t e, const char *what) { unpin(); return fail(c, DSPI_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+    hipError_t he;
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        const uint32_t r0 = ch * rows_per, r1 = std::min(c->n_wg, r0 + rows_per);
+        const size_t s0 = (size_t)r0 * row, s1 = std::min((size_t)r1 * row, (size_t)c->n_streams);      // streams of the chunk
+        hipStream_t sin = n_chunks > 1 ? c->hs_in : c->hs, sout = n_chunks > 1 ? c->hs_out : c->hs;
+        if ((he = hipMemcpyAsync(static_cast<char *>(c->d_in) + s0 * frames * bpf, static_cast<const char *>(pcm_in) + s0 * frames * bpf, (s1 - s0) * frames * bpf,
+                                 hipMemcpyHostToDevice, sin)) != hipSuccess) return fail_hip(he, "H2D");
+        if (n_chunks > 1) {
+            if ((he = hipEventRecord(c->pipe_events[2 * ch], sin)) != hipSuccess || (he = hipStreamWaitEvent(c->hs, c->pipe_events[2 * ch], 0)) != hipSuccess) return fail_hip(he, "event");
+        }
+        if ((rc = launch_rows(r0, r1))) { unpin(); return rc; }
+        if (n_chunks > 1) {
+            if ((he = hipEventRecord(c->pipe_events[2 * ch + 1], c->hs)) != hipSuccess || (he = hipStreamWaitEvent(sout, c->pipe_events[2 * ch + 1], 0)) != hipSuccess) return fail_hip(he, "event");
+        }
+        // tiled words: whole tiles [tile][...]; stream-major: [stream][...] — either way a row range is one contiguous piece
+        const size_t t0 = tiled ? (size_t)r0 * row : s0, t1 = tiled ? (size_t)r1 * row : s1;
+        if (out->pairs) {
+            const size_t per = tiled ? (size_t)(c->sm.n_out - 1) * frames * 4 : (size_t)c->sm.n_pairs * frames * 8;
+            if ((he = hipMemcpyAsync(reinterpret_cast<char *>(out->pairs) + t0 * per, reinterpret_cast<char *>(c->d_pairs) + t0 * per, (t1 - t0) * per, hipMemcpyDeviceToHost, sout)) != hipSuccess) return fail_hip(he, "D2H pairs");
+        }
+        if (out->sub) {
+            const size_t per = frames * 4;
+            if ((he = hipMemcpyAsync(reinterpret_cast<char *>(out->sub) + t0 * per, reinterpret_cast<char *>(c->d_sub) + t0 * per, (t1 - t0) * per, hipMemcpyDeviceToHost, sout)) != hipSuccess) return fail_hip(he, "D2H sub");
+        }
+        if (out->peaks) {
+            const size_t per = (size_t)n_blocks * c->sm.n_ch * 2;
+            if ((he = hipMemcpyAsync(reinterpret_cast<char *>(out->peaks) + s0 * per, reinterpret_cast<char *>(c->d_peaks) + s0 * per, (s1 - s0) * per, hipMemcpyDeviceToHost, sout)) != hipSuccess) return fail_hip(he, "D2H peaks");
+        }
+    }
+    if (n_chunks > 1) {
+        if ((he = hipStreamSynchronize(c->hs_out)) != hipSuccess) return fail_hip(he, "sync");
+        if ((he = hipStreamSynchronize(c->hs_in)) != hipSuccess) return fail_hip(he, "sync");
+    }
+    if ((he = hipStreamSynchronize(c->hs)) != hipSuccess) return fail_hip(he, "sync");
+    unpin();
     return DSPI_OK;
 }
 

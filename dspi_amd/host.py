@@ -194,14 +194,17 @@ class Dspi:
         return int(self.L.dspi_tile_streams(self.h))
 
     def process_host(self, pcm: np.ndarray, n_blocks: int, block_len: int, bit_depth: int = 16,
-                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False):
+                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False, out=None):
         """Host-memory convenience path (tests): pcm = int16 [streams][frames][2] or uint8 [streams][frames*6].
         Returns (pairs [S][P][F][2], sub [S][F], peaks [S][blocks][C]); with tiled=True the sample words come back in
         the DSPI_OUT_TILED layout: pairs [tiles][outputs][F][R], sub [tiles][F][R] (see untile())."""
         S, F = self.n_streams, n_blocks * block_len
         pcm = np.ascontiguousarray(pcm)
         assert pcm.nbytes == S * F * (6 if bit_depth == 24 else 4), (pcm.shape, S, F)
-        if tiled:
+        if out is not None:      # the arrays of an earlier call, written in place (a host that reuses its buffers: no fresh pages to fault in)
+            pairs, sub, peaks = out
+            want_pairs, want_sub, want_peaks = pairs is not None, sub is not None, peaks is not None
+        elif tiled:
             R = self.tile_streams(); nt = (S + R - 1) // R
             pairs = np.zeros((nt, self.P * 2, F, R), dtype=np.int32) if want_pairs else None
             sub = np.zeros((nt, F, R), dtype=np.int32) if want_sub else None

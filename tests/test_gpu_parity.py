@@ -506,6 +506,42 @@ def test_full_size_stream_major_groups_agree(flavor, fs, B, blocks):
     d.close()
 
 
+@pytest.mark.parametrize("flavor,tiled", [(W.F32_FMA, False), (1, True), (0, False), (0, True)])
+def test_host_buffer_pipeline_chunks(flavor, tiled):
+    """dspi_process on HOST buffers large enough to take the chunked pipeline (rows cut into chunks, H2D / kernels / D2H of consecutive
+    chunks on three streams, the caller's arrays pinned for the call): every word, sub word and peak must equal what a second context
+    produces from device buffers in one piece, over two calls, and sampled streams must equal the oracle."""
+    import torch
+    fs, B, blocks, S = 96000, 96, 20, 1024
+    dev = torch.device("cuda", 0)
+    dh, dd = Dspi(flavor, S, device=0), Dspi(flavor, S, device=0)
+    for d in (dh, dd):
+        d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(WL.full_chain_blob(int(flavor))) == 0
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
+    R = dh.tile_streams(); nt = (S + R - 1) // R
+    N, P, C = dh.N, dh.P, dh.C
+    frames = B * blocks
+    host_out = None
+    for c in range(2):
+        part = np.ascontiguousarray(pcm[:, c * frames:(c + 1) * frames])
+        host_out = dh.process_host(part, blocks, B, tiled=tiled, out=host_out)          # the second call reuses the arrays
+        t_in = torch.from_numpy(part).to(dev)
+        shape_p = (nt, 2 * P, frames, R) if tiled else (S, P, frames, 2)
+        shape_s = (nt, frames, R) if tiled else (S, frames)
+        tp = torch.zeros(shape_p, dtype=torch.int32, device=dev); ts = torch.zeros(shape_s, dtype=torch.int32, device=dev)
+        tk = torch.zeros((S, blocks, C), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        dd.process_device(t_in.data_ptr(), blocks, B, 16, tp.data_ptr(), ts.data_ptr(), tk.data_ptr(), tiled=tiled); dd.sync()
+        assert np.array_equal(host_out[0], tp.cpu().numpy()), f"call {c}: pair words of the chunked host path differ from the device path"
+        assert np.array_equal(host_out[1], ts.cpu().numpy()) and np.array_equal(host_out[2].view(np.int16), tk.cpu().numpy()), c
+    pairs, sub = (dh.untile(host_out[0], host_out[1]) if tiled else (host_out[0], host_out[1]))
+    for s in (0, R - 1, R, 2 * R + 5, S // 2, S - 1):
+        (rp, rs, rk, _), status = oracle_run(flavor, fs, -20 * 256, WL.full_chain_blob(int(flavor)), pcm[s], blocks * 2, B, 16)
+        assert np.array_equal(rp[:, frames:, :], pairs[s]) and np.array_equal(rs[frames:], sub[s]) and np.array_equal(rk[blocks:], host_out[2][s]), s
+        assert status == dh.status(s)
+    dh.close(); dd.close()
+
+
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_flash_dump_boots_device_context(flavor):
     """SURVEY 8f-4 on the GPU: dspi_load_flash_dump on a DEVICE context (v2 directory, v1 directory, corrupt selected slot -> factory
