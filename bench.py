@@ -176,9 +176,9 @@ def chain_workload(name):
                     text="BASELINE config 3: full RP2350 chain (preamp+loudness+master PEQ+leveller/lookahead+crossfeed+2x9 matrix+9x10-band PEQ+gain+"
                          "9 delay lines), 96 kHz, 96-frame packets, int16 in, 4 S/PDIF pairs + PDM sub out")
     if name in ("2", "2b"):
-        return dict(flavor=1, fs=48000, B=48, streams=4096, blocks=2000, channels=2, vol=-10 * 256, blob=WL.config2_blob(name == "2b"),
+        return dict(flavor=1, fs=48000, B=48, streams=4096, blocks=2000, channels=2, vol=-10 * 256, blob=WL.config2_blob(name == "2b"), enabled_only=True,
                     text="BASELINE config 2: 4 096 streams, 48 kHz, 48-frame packets, 2 000 packets per launch, master L/R 10-band PEQ only (%s), "
-                         "outputs 0-1 pass-through" % ("all-biquad variant, bands 6.5-20 kHz" if name == "2b" else "SVF below 6.4 kHz + biquad above"))
+                         "outputs 0-1 pass-through; DSPI_OUT_ENABLED_ONLY: the three disabled pairs and the sub are not zero-filled" % ("all-biquad variant, bands 6.5-20 kHz" if name == "2b" else "SVF below 6.4 kHz + biquad above"))
     if name == "5":
         return dict(flavor=0, fs=48000, B=48, streams=16384, blocks=50, channels=7, vol=-20 * 256, blob=WL.full_chain_blob(0),
                     text="BASELINE config 5: RP2040 Q28 fixed-point 7-channel chain (5 outputs, delays <= 40 ms), 16 384 streams, 48 kHz, 48-frame packets")
@@ -368,14 +368,16 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         peaks = torch.empty((S, NB, 2 + N), dtype=torch.int16, device=dev)
         torch.cuda.synchronize()
         elapsed, kernel_ms = timed_steps(args, torch, dist, backend, dev, ctx,
-                                         lambda: ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled))
+                                         lambda: ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled,
+                                                                    enabled_only=bool(w.get("enabled_only"))))
+        plan = ctx.launch_plan()
         ctx.close()
         del pairs, sub, peaks
         torch.cuda.empty_cache()
         n_total = total if args.scaling == "strong" else total * world
         fps = float(n_total) * frames * args.steps / elapsed
         return dict(contract=contract if flavor == 1 else "integer", out_layout=layout, input=inp, frames_per_s=fps, value=fps * CH,
-                    ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms)
+                    ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms, latency_layout=plan.get("latency_layout", 0) > 0)
 
     primary = measure(args.contract, args.out_layout, args.input)
     also = []
@@ -411,6 +413,8 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         kname = "chain_kernel_pk<false, true, false, %s, %s, %s, %s>" % ("true" if args.out_layout == "tiled" else "false", "true" if args.contract == "fma" else "false",
                                                                          "true" if w.get("perstream") else "false", "true" if w.get("perstream") == "eq" else "false")
         if CH == 2: kname = kname.replace("<false, true", "<false, false")
+        if primary.get("latency_layout"):      # small launches of presets without leveller / output EQ: the skewed cascade (dspi_chain_skew.inc)
+            kname = "chain_kernel_skew<%s, false>" % ("true" if args.contract == "fma" else "false")
     else:
         # wave layout by launch size (dspi_kernels.hip chain_kernel NW): seven waves up to one 64-stream workgroup per CU, four beyond
         cus = torch.cuda.get_device_properties(dev).multi_processor_count

@@ -24,6 +24,7 @@ struct KArgs {
     uint32_t tiled_out;      // DSPI_OUT_TILED: pairs = [tile][output][frames][row], sub = [tile][frames][row] (row = StateMap::row)
     uint32_t *xwords;        // packed float kernel, stream-major output: exchange area [n_wg][2][kMaxOut][kChunk][128] words (or null: scattered stores)
     const float *vals;       // packed float kernel, per-lane values: value tiles [n_wg][kPvTileFloats] (dspi_image.h) or null
+    uint32_t skip_silent;    // DSPI_OUT_ENABLED_ONLY: sample words of silent outputs (a disabled S/PDIF pair, the sub while it is off) need not be stored
     uint32_t fma;            // float flavour: the context's contract is DSPI_FLOAT_CONTRACT_FMA (selects the kernel family at launch)
 };
 
@@ -34,6 +35,8 @@ size_t chain_lds_bytes(int flavor, int packed);
 // packed 3 = packed float kernel with per-lane VALUES: one item per row whose streams share a structure, WgItem::image = any
 // image of the row (read for the structure only), numbers from args.vals; packed 4 = the same for rows whose presets have identical
 // FILTERS (band coefficients from the image's scalars, everything else from args.vals)
+// packed 5 = the latency layout of the float chain (dspi_chain_skew.inc): items as for packed 1, images with the leveller off and no
+// active output EQ, launches small enough to leave the chip underfilled (dspi_capi.cpp decides)
 // leveller_on: IF_LEVELLER_ON of every image in args.items (the host groups them; the packed kernel is specialised on it)
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,

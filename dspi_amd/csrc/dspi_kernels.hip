@@ -1140,6 +1140,7 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const S
 }
 
 #include "dspi_chain_pk.inc"
+#include "dspi_chain_skew.inc"
 
 // ==========================================================================================
 // the one-stream-per-lane kernel (Q28 flavour; float flavour: lanes whose two streams differ in image)
@@ -1614,6 +1615,30 @@ DSPI_PK_FAMILY(4, true, true, false)
 DSPI_PK_FAMILY(5, true, true, true)
 #endif
 
+// the latency layout of the float chain (dspi_chain_skew.inc): part 7
+hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, hipStream_t stream);
+#if !defined(DSPI_PART) || DSPI_PART == 7
+hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    const dim3 grid(n_items * (64 / kSkPairs)), block(64 * kSkWaves);
+    const size_t lds = sizeof(SkShared);
+    static bool attr_set[kMaxDevices] = {};      // per device, see launch_chain_t
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
+    if (!attr_set[dev] || dev == kMaxDevices - 1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const bool p24 = args.bit_depth == 24;
+    if (args.fma) { if (p24) hipLaunchKernelGGL((chain_kernel_skew<true, true>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<true, false>), grid, block, lds, stream, args); }
+    else { if (p24) hipLaunchKernelGGL((chain_kernel_skew<false, true>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<false, false>), grid, block, lds, stream, args); }
+    return hipGetLastError();
+}
+#endif
+
 #ifdef DSPI_PART_MAIN
 // ---- value tiles of the per-lane-value rows (dspi_image.h): one thread per (row, word, column) ----
 __global__ void pv_clear_kernel(const uint32_t *rows, float *vals, uint32_t all_differ) {
@@ -1673,6 +1698,7 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
     // per-lane images (float always; Q28 rows with several presets)
     if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
     // float: the context's contract (DSPI_FLOAT_CONTRACT_FMA) picks the kernel family
+    if (packed == 5) return launch_chain_skew(args, n_items, stream);
     if (packed != 1 && packed != 3 && packed != 4) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
     if (packed == 3) return args.fma ? launch_chain_pk_f5(args, leveller_on, n_items, stream) : launch_chain_pk_f2(args, leveller_on, n_items, stream);
     if (packed == 4) return args.fma ? launch_chain_pk_f4(args, leveller_on, n_items, stream) : launch_chain_pk_f1(args, leveller_on, n_items, stream);

@@ -41,9 +41,10 @@
 extern "C" {
 #endif
 
-#define DSPI_ABI_VERSION 4   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
+#define DSPI_ABI_VERSION 5   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
                               * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1,
-                              * dspi_debug_launch_plan, dspi_debug_image_count (additions only) */
+                              * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, dspi_debug_launch_plan counts[5]
+                              * (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -76,6 +77,11 @@ extern "C" {
 /* dspi_process flags */
 #define DSPI_MEM_DEVICE 0x1u       /* pcm_in and every pointer in dspi_out are device pointers (zero-copy) */
 #define DSPI_OUT_TILED 0x2u        /* pairs / sub use the device-native tiled layout described at dspi_out */
+#define DSPI_OUT_ENABLED_ONLY 0x4u /* the caller does not read the sample words of SILENT outputs — an S/PDIF pair whose two outputs are
+                                    * disabled (the firmware zero-fills it, usb_audio.c:930-933), the sub while it is disabled or Core 1
+                                    * runs the EQ worker — so the library may leave those parts of pairs / sub unwritten instead of storing
+                                    * zeros (36 of the 40 bytes per frame for a preset with one live pair).  Peaks, status and every live
+                                    * output are unaffected.  Honoured by the float chain's latency layout; the other kernels write the zeros. */
 
 typedef struct dspi_ctx dspi_ctx;
 
@@ -213,7 +219,8 @@ int dspi_debug_image(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
 /* Which kernel the context's rows currently go to (after the last dspi_process): work items per launch list, counts[5] =
  * {Q28 shared image, packed float shared image, one-stream kernel with per-lane parameter images, packed float with per-lane values
  * incl. band coefficients, packed float with per-lane values and shared band coefficients}.  Tests use it to prove that a scenario
- * ran on the path it was written for.  Returns 5 or a negative DSPI_E_*. */
+ * ran on the path it was written for.  With n_counts >= 6, counts[5] = items of the float chain's latency layout (small launches of
+ * presets with the leveller off and no output EQ).  Returns the number of counts written (5 or 6) or a negative DSPI_E_*. */
 int dspi_debug_launch_plan(dspi_ctx *ctx, uint32_t *counts, size_t n_counts);
 /* Number of distinct parameter objects the context holds (streams share one until a per-stream call separates them; streams that
  * received the same whole state again through broadcast calls are folded back, here or at the next dspi_process).  Works on

@@ -73,6 +73,115 @@ def test_full_chain(flavor, fs, B, depth):
     compare(flavor, fs, B, 24, 85, WL.full_chain_blob(flavor), depth=depth)
 
 
+def _latency_blob(xfeed=True, loud=True, delays=(0.0, 0.3, 1.7, 0.0, 95.0, 0.05, 12.0, 0.0, 3.0)):
+    """A preset of the latency layout's class: master PEQ (+ loudness, crossfeed), leveller off, outputs routed, gained and delayed
+    but without EQ; output 3 muted, output 5 disabled, crosspoint patterns both / left only / right only / inverted."""
+    b = WL.config2_blob(False)
+    b["preamp"]["preamp_db"][:] = (-2.0, -4.5)
+    b["global_"]["loudness_enabled"] = 1 if loud else 0
+    b["crossfeed"]["enabled"], b["crossfeed"]["preset"], b["crossfeed"]["itd_enabled"] = (1 if xfeed else 0), 1, 1
+    for o in range(9):
+        out = b["outputs"][o]
+        out["enabled"] = 0 if o == 5 else 1
+        out["mute"] = 1 if o == 3 else 0
+        out["gain_db"] = -0.5 * o
+        out["delay_ms"] = delays[o]
+        for inp in (0, 1):
+            xp = b["crosspoints"][inp, o]
+            xp["enabled"] = 1 if (o % 3 == 0 or (o % 3 == 1 and inp == 0) or (o % 3 == 2 and inp == 1)) else 0
+            xp["gain_db"] = -3.0 - inp
+        b["crosspoints"][1, 6]["phase_invert"] = 1
+    return b
+
+
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+@pytest.mark.parametrize("fs,B,depth", [(48000, 48, 16), (96000, 96, 24), (44100, 45, 16), (44100, 44, 24), (48000, 1, 16), (48000, 7, 16), (48000, 97, 16), (96000, 192, 16)])
+def test_latency_layout(flavor, fs, B, depth, monkeypatch):
+    """The float chain's latency layout (dspi_chain_skew.inc: the EQ cascade skewed across lanes, outputs frame-parallel), forced for
+    every eligible image: master PEQ with SVF and biquad bands, loudness shelves, crossfeed, delays shorter and longer than a packet and
+    at the aliasing maximum, muted / disabled outputs, every packet length class, both input depths, ragged stream count, three calls."""
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    blob = _latency_blob()
+    blocks = 24 if B >= 44 else 150
+    S = 37          # 18 pairs + a pair that holds one stream: three workgroup parts, one of them partly filled
+    d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-7 * 256); assert d.load_bulk(blob) == 0
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm)
+    per = blocks // 3
+    unit = B if depth == 16 else B * 6                 # elements of the second axis per packet: frames, or bytes of packed 24-bit frames
+    outs = [d.process_host(np.ascontiguousarray(data[:, c * per * unit:(c + 1) * per * unit]), per, B, depth) for c in range(3)]
+    assert d.launch_plan()["latency_layout"] > 0 and d.launch_plan()["packed_shared"] == 0
+    pairs = np.concatenate([o[0] for o in outs], axis=2); sub = np.concatenate([o[1] for o in outs], axis=1); peaks = np.concatenate([o[2] for o in outs], axis=1)
+    for s in range(S):
+        o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-7 * 256); assert o.load_bulk(blob) == 0
+        rp, rs, rk, _ = o.process(data[s][:per * 3 * unit], per * 3, B, depth)
+        assert np.array_equal(rp, pairs[s]), f"pairs differ, stream {s}: {np.argwhere(rp != pairs[s])[:3].tolist()}"
+        assert np.array_equal(rs, sub[s]) and np.array_equal(rk, peaks[s]), s
+        assert o.status() == d.status(s), s
+    d.close()
+
+
+def test_enabled_only_leaves_silent_outputs_unwritten(monkeypatch):
+    """DSPI_OUT_ENABLED_ONLY (include/dspi.h): silent outputs (disabled pairs, the sub while off) may stay unwritten — the latency
+    layout skips their stores —, every live word, peak and status byte is what it is without the flag."""
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    fs, B, blocks, S = 48000, 48, 9, 40
+    blob = WL.config2_blob(False)
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    ref = Dspi(W.F32_FMA, S, device=0); ref.set_rate(fs); ref.set_volume(-10 * 256); assert ref.load_bulk(blob) == 0
+    rp, rs, rk = ref.process_host(pcm, blocks, B)
+    d = Dspi(W.F32_FMA, S, device=0); d.set_rate(fs); d.set_volume(-10 * 256); assert d.load_bulk(blob) == 0
+    import torch
+    dev = torch.device("cuda", 0)
+    tp = torch.full((S, 4, B * blocks, 2), 0x5A5A5A5A, dtype=torch.int32, device=dev); ts = torch.full((S, B * blocks), 0x5A5A5A5A, dtype=torch.int32, device=dev)
+    tk = torch.zeros((S, blocks, 11), dtype=torch.int16, device=dev)
+    t_in = torch.from_numpy(pcm).to(dev)
+    torch.cuda.synchronize()
+    d.process_device(t_in.data_ptr(), blocks, B, 16, tp.data_ptr(), ts.data_ptr(), tk.data_ptr(), enabled_only=True); d.sync()
+    p, s_, k = tp.cpu().numpy(), ts.cpu().numpy(), tk.cpu().numpy().view(np.uint16)
+    assert d.launch_plan()["latency_layout"] > 0
+    assert np.array_equal(p[:, 0], rp[:, 0]) and np.array_equal(k, rk)
+    assert int(np.abs(rp[:, 1:]).max()) == 0 and int(np.abs(rs).max()) == 0            # what the flag lets the library skip is silence
+    assert bool((p[:, 1:] == 0x5A5A5A5A).all()) and bool((s_ == 0x5A5A5A5A).all())     # ... and on device buffers it was skipped
+    for s in (0, 1, S - 1): assert ref.status(s) == d.status(s)
+    ref.close(); d.close()
+
+
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+def test_latency_layout_mixed_with_other_kernels(flavor, monkeypatch):
+    """One context, three kernels in a call: most stream pairs share the latency-class preset (latency layout), a few streams get presets
+    of their own (per-lane kernels), and one group gets the leveller switched on (packed kernel).  Then the shared preset changes class
+    (an output EQ band becomes active): the context moves to the packed kernel on the same state arrays, mid-stream; tiled words."""
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    fs, B, blocks, S = 48000, 48, 12, 300
+    blob = _latency_blob(xfeed=True, loud=False)
+    d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-9 * 256); assert d.load_bulk(blob) == 0
+    def special(x, s):
+        if s in (5, 130): x.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -8.0)) if isinstance(x, Oracle) else x.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -8.0), stream=s)
+    for s in (5, 130): special(d, s)
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
+    o1 = d.process_host(np.ascontiguousarray(pcm[:, :B * blocks]), blocks, B, tiled=True)
+    plan = d.launch_plan()
+    assert plan["latency_layout"] > 0 and plan["packed_per_lane_values"] + plan["one_stream_per_lane_images"] > 0, plan      # rows 0-1: per-lane values, row 2: latency layout
+    p1, s1 = d.untile(o1[0], o1[1])
+    # class change for everyone: output 1 gets a live EQ band -> packed kernel from here on
+    eq = struct.pack("<BBBBfff", 3, 2, W.FILTER_PEAKING, 0, 900.0, 1.2, 4.0)
+    d.vendor_set(W.REQ["SET_EQ_PARAM"], 0, eq)
+    o2 = d.process_host(np.ascontiguousarray(pcm[:, B * blocks:]), blocks, B, tiled=True)
+    assert d.launch_plan()["latency_layout"] == 0
+    p2, s2 = d.untile(o2[0], o2[1])
+    for s in (0, 4, 5, 6, 129, 130, 131, 255, 256, S - 1):
+        o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-9 * 256); assert o.load_bulk(blob) == 0
+        special(o, s)
+        rp, rs, rk, _ = o.process(pcm[s][:B * blocks], blocks, B)
+        assert np.array_equal(rp, p1[s]) and np.array_equal(rs, s1[s]) and np.array_equal(rk, o1[2][s]), ("first call", s)
+        o.vendor_set(W.REQ["SET_EQ_PARAM"], 0, eq)
+        rp, rs, rk, _ = o.process(pcm[s][B * blocks:], blocks, B)
+        assert np.array_equal(rp, p2[s]) and np.array_equal(rs, s2[s]) and np.array_equal(rk, o2[2][s]), ("after the class change", s)
+        assert o.status() == d.status(s)
+    d.close()
+
+
 @pytest.mark.parametrize("waves", ["4", "7", None])
 def test_q28_wave_layouts(waves, monkeypatch):
     """The Q28 kernel's two wave layouts (four waves: two outputs per wave; seven: one output per wave, for launches of at most one
