@@ -121,6 +121,9 @@ Params *writable(dspi_ctx *c, int32_t stream) {
     return c->images[(size_t)idx].get();
 }
 
+// A broadcast call may make separate images equal again (the same whole state for everyone, or a request that removes the only
+// difference): it asks for the fold-back pass at the next commit.  When that pass finds nothing to fold it leaves the images as they
+// were — no re-upload, no rebuilt lists (merge_images) —, so a broadcast volume change on 65 536 distinct presets costs one hashing pass.
 template <class F>
 int for_targets(dspi_ctx *c, int32_t stream, F f) {
     if (!c) return DSPI_E_INVAL;
@@ -146,9 +149,11 @@ void merge_images(dspi_ctx *c) {
     std::vector<size_t> live;
     for (size_t i = 0; i < ni; i++) if (c->image_refs[i] > 0) live.push_back(i);
     if (ni < 2) return;
+    std::vector<uint8_t> was_dirty(ni, 0);
     for (size_t i : live) {
         Params &p = *c->images[i];
-        p.dirty = true;                                            // everything is uploaded again below; the flag is part of the bytes
+        was_dirty[i] = p.dirty ? 1 : 0;
+        p.dirty = true;                                            // the flag is part of the bytes that are compared; restored below when nothing merges
         if (p.ops.reset_all_eq) memset(p.ops.reset_band, 0, sizeof p.ops.reset_band);      // the wipe covers every band (state_ops_kernel): which single bands a stream's history also marked does not matter
     }
     std::vector<uint64_t> h(ni, 0);
@@ -177,7 +182,10 @@ void merge_images(dspi_ctx *c) {
         if (to < 0) { to = (int32_t)keep.size(); keep.push_back(i); cands.push_back(i); }
         remap[i] = to;
     }
-    if (keep.size() == ni) return;                                // nothing equal, nothing dead
+    if (keep.size() == ni) {                                      // nothing equal, nothing dead: nothing to upload that was not dirty already
+        for (size_t i : live) c->images[i]->dirty = was_dirty[i] != 0;
+        return;
+    }
     std::vector<std::unique_ptr<Params>> images;
     for (size_t i : keep) images.push_back(std::move(c->images[i]));
     c->images = std::move(images);
@@ -312,6 +320,19 @@ int rebuild_launch_lists(dspi_ctx *c) {
             }
         for (const auto &r : rows_f)
             if (r.second.n > 1 && r.second.same && (r.second.m0 & r.second.m1)) c->row_pv[r.first] = r.second.same_bands ? 2 : 1;
+        // "identical filters" (row_pv 2: the kernel takes the band coefficients of the row's first image for every stream) was decided
+        // on two 64-bit hashes; back it with the words themselves before it can cost bit-exactness
+        std::unique_ptr<DevImage> ref(new DevImage), cur(new DevImage);
+        uint32_t ref_row = 0xffffffffu;
+        for (size_t i = 0; i < c->images.size(); i++)
+            for (const WgItem &it : c->image_items[0][i]) {
+                if (c->row_pv[it.wg] != 2) continue;
+                const RowAcc &r = rows_f[it.wg];
+                if (r.first == i) continue;
+                if (ref_row != it.wg) { c->images[r.first]->build_image(*ref); ref_row = it.wg; }
+                c->images[i]->build_image(*cur);
+                if (memcmp(ref->eq, cur->eq, sizeof ref->eq) != 0 || memcmp(ref->loud, cur->loud, sizeof ref->loud) != 0) c->row_pv[it.wg] = 1;
+            }
     }
     for (int lev = 0; lev < 2; lev++) c->launch_items[lev][5].clear();
     for (int lev = 0; lev < 2; lev++)
@@ -550,8 +571,8 @@ extern "C" {
 int dspi_abi_version(void) { return DSPI_ABI_VERSION; }
 
 int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) {
-    const bool fma = (flavor & DSPI_FLOAT_CONTRACT_FMA) != 0;
-    flavor &= ~DSPI_FLOAT_CONTRACT_FMA;
+    const bool fma = (flavor & DSPI_FLOAT_CONTRACT_FMA) != 0, populated = (flavor & DSPI_BOOT_POPULATED_FLASH) != 0;
+    flavor &= ~(DSPI_FLOAT_CONTRACT_FMA | DSPI_BOOT_POPULATED_FLASH);
     if (!out || (flavor != DSPI_FLAVOR_RP2040_Q28 && flavor != DSPI_FLAVOR_RP2350_F32) || n_streams == 0) return DSPI_E_INVAL;
     if (fma && flavor != DSPI_FLAVOR_RP2350_F32) return DSPI_E_INVAL;      // the RP2040 has no FPU: nothing to contract
     dspi_ctx *c = new (std::nothrow) dspi_ctx();
@@ -562,7 +583,7 @@ int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) 
     c->sm = make_state_map(flavor);
     c->n_wg = (n_streams + (uint32_t)c->sm.row - 1) / (uint32_t)c->sm.row;
     c->fma = fma;
-    c->images.push_back(std::make_unique<Params>(flavor, fma));
+    c->images.push_back(std::make_unique<Params>(flavor, fma, !populated));
     c->image_refs.push_back(n_streams);
     c->stream_image.assign(n_streams, 0);
     *out = c;
@@ -663,6 +684,17 @@ int dspi_vendor_get(dspi_ctx *c, int32_t stream, uint8_t req, uint16_t wValue, v
         if (cap < 1) return DSPI_E_SHORT;
         *(uint8_t *)buf = 0;
         return 1;
+    }
+    if (req == 0xC0) {   // REQ_SET_OUTPUT_TYPE: answered from a copy unless it really changes a slot's type (no clone, no mute for a no-op or a refusal)
+        if (cap < 1) return DSPI_E_SHORT;
+        const uint8_t slot = wValue & 0xFF, type = (wValue >> 8) & 0xFF;
+        bool changes = false;
+        for (size_t i = 0; i < c->images.size() && !changes; i++) {
+            if (stream == DSPI_ALL_STREAMS ? c->image_refs[i] == 0 : (size_t)c->stream_image[(size_t)stream] != i) continue;
+            const Params &r = *c->images[i];
+            changes = slot < r.n_pairs && type <= 1 && type != r.output_types[slot];
+        }
+        if (!changes) { Params view = readable(c, stream); return view.vendor_get(req, wValue, buf, cap, peaks, &clip); }
     }
     if (req == 0xD6 || req == 0xC0) {   // REQ_SAVE_MASTER_VOLUME mutates the directory copy, REQ_SET_OUTPUT_TYPE the slot type (+ pipeline mute)
         return for_targets(c, stream, [&](Params &p) { int r = p.vendor_get(req, wValue, buf, cap, peaks, &clip); return r < 0 ? r : 0; }) == 0 ? 1 : DSPI_E_SHORT;

@@ -164,8 +164,9 @@ int32_t f2i_sat(float f) {
 // ============================================================================================
 // construction / boot
 // ============================================================================================
-Params::Params(int fl, bool fma) {
+Params::Params(int fl, bool fma, bool first_boot_) {
     memset((void *)this, 0, sizeof(*this));
+    first_boot = first_boot_;
     flavor = fl;
     fma_contract = fma && fl;            // the RP2040 has no FPU, hence nothing to contract
     StateMap m = make_state_map(fl);
@@ -205,8 +206,9 @@ void Params::boot() {
     memset(&ops, 0, sizeof(ops));     // nothing has run yet: state starts zeroed by the context
     // First boot on an erased flash writes the fresh directory (preset_boot_load -> dir_flush, flash_storage.c:1086-1090),
     // and every flash_write_sector re-arms the preset mute for flash_mute_hold_samples() = max(10 ms, 512) samples at the
-    // power-on rate of 44.1 kHz (:262-266, :349-350): a new device starts with 512 muted samples and the fade-in.
-    pipeline_mute(512);
+    // power-on rate of 44.1 kHz (:272-276, :347-348): a new device starts with 512 muted samples and the fade-in.  A device whose
+    // flash already holds a directory writes nothing at boot and does not mute (DSPI_BOOT_POPULATED_FLASH, include/dspi.h).
+    if (first_boot) pipeline_mute(512);
     dirty = true;
 }
 
@@ -852,7 +854,7 @@ int Params::load_slot(const void *image, size_t len, int expect_slot) {
     ops.zero_delay_lines = 1;              // flash_storage.c:832
     transition_core1();
     // preset_load ends by writing the directory (flash_storage.c:846-847) and every flash_write_sector re-arms the mute
-    // for flash_mute_hold_samples() = max(10 ms, 512 samples) (:262-266, :349-350)
+    // for flash_mute_hold_samples() = max(10 ms, 512 samples) (:272-276, :347-348)
     {
         uint64_t hold = ((uint64_t)freq * 10u + 999u) / 1000u;
         pipeline_mute(hold < 512u ? 512u : (uint32_t)hold);

@@ -51,7 +51,7 @@ struct LoudCoeffs { Word c[6]; bool bypass; };   // f32: sva1..3, svm0..2 ; q28:
 
 class Params {
 public:
-    explicit Params(int flavor, bool fma_contract = false);
+    explicit Params(int flavor, bool fma_contract = false, bool first_boot = true);
 
     // ---- operations (each cites the reference entry point in dspi_params.cpp) ----
     void boot();
@@ -72,6 +72,7 @@ public:
 
     // ---- firmware-visible parameter state ----
     int flavor;
+    bool first_boot;                    // power-on of a device with an erased flash: the boot writes the preset directory, which arms the 512-sample mute
     bool fma_contract;                  // float flavour as the firmware is built: GCC's FMA contraction (dspi.h DSPI_FLOAT_CONTRACT_FMA)
     int n_ch, n_out, n_pairs, n_pins, max_delay;
     Recipe recipes[kMaxCh][kStoredBands];

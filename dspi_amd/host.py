@@ -84,14 +84,15 @@ def lib() -> C.CDLL:
 class Dspi:
     """`n_streams` DSPi devices on one GPU (device=None: host-only, parameter surface only)."""
 
-    def __init__(self, flavor: int, n_streams: int, device: int | None = 0, fma: bool = False):
-        """fma: the float flavour with the firmware build's FMA contraction (DSPI_FLOAT_CONTRACT_FMA, include/dspi.h)."""
+    def __init__(self, flavor: int, n_streams: int, device: int | None = 0, fma: bool = False, populated_flash: bool = False):
+        """fma: the float flavour with the firmware build's FMA contraction (DSPI_FLOAT_CONTRACT_FMA, include/dspi.h).
+        populated_flash: DSPI_BOOT_POPULATED_FLASH — devices that do not boot for the first time (no first-boot preset mute)."""
         self.L = lib()
         self.h = C.c_void_p()
         fma = bool(fma or getattr(flavor, "fma", False))      # tests pass wire.F32_FMA: the int 1 carrying the contract
         flavor = int(flavor)
         self.fma = fma
-        rc = self.L.dspi_create(C.byref(self.h), flavor | (0x100 if fma else 0), n_streams, -1 if device is None else device)
+        rc = self.L.dspi_create(C.byref(self.h), flavor | (0x100 if fma else 0) | (0x200 if populated_flash else 0), n_streams, -1 if device is None else device)
         if rc != 0:
             raise DspiError(rc, "dspi_create")
         self.flavor, self.n_streams = flavor, n_streams

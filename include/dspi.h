@@ -43,7 +43,7 @@ extern "C" {
 
 #define DSPI_ABI_VERSION 5   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
                               * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1,
-                              * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, dspi_debug_launch_plan counts[5]
+                              * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, DSPI_BOOT_POPULATED_FLASH, dspi_debug_launch_plan counts[5]
                               * (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
@@ -58,6 +58,13 @@ extern "C" {
  * corresponding way (oracle/Makefile, tests/test_oracle_vs_fw.py); the fused one needs a third fewer vector instructions. */
 #define DSPI_FLOAT_CONTRACT_FMA 0x100
 #define DSPI_FLAVOR_RP2350_F32_FMA (DSPI_FLAVOR_RP2350_F32 | DSPI_FLOAT_CONTRACT_FMA)
+/* OR into the flavour of dspi_create: what the power-on models.  By default every stream is a device that boots for the FIRST time on an
+ * erased flash: preset_boot_load writes the fresh preset directory (flash_storage.c:1086-1090), and every flash sector write arms the
+ * preset mute for flash_mute_hold_samples() = max(10 ms, 512) samples (:272-276, :347-348) — so a new context starts with 512 muted
+ * samples and the fade-in (5 to 12 ms of silence / ramp at the start of the first packets).  With DSPI_BOOT_POPULATED_FLASH the streams
+ * are devices whose flash already holds a directory: nothing is written at boot, audio starts unmuted; load the preset such a device
+ * would have booted with dspi_load_flash_dump / dspi_load_preset_slot. */
+#define DSPI_BOOT_POPULATED_FLASH 0x200
 
 #define DSPI_ALL_STREAMS (-1)
 #define DSPI_DEVICE_NONE (-1)      /* host-only context: parameter surface works, dspi_process fails */

@@ -651,6 +651,32 @@ def test_host_buffer_pipeline_chunks(flavor, tiled):
     dh.close(); dd.close()
 
 
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+def test_boot_from_populated_flash_has_no_first_boot_mute(flavor):
+    """DSPI_BOOT_POPULATED_FLASH: a context of devices that do NOT boot for the first time starts unmuted — the default context arms the
+    512-sample preset mute the firmware's first boot arms by writing its directory (flash_storage.c:1086-1090, :347-348).  Checked
+    against the reference's own boot path: the firmware build booted from a flash that holds a directory and the factory-default
+    preset in slot 0 (no write, no mute) plays, from the first frame, what the flagged context plays."""
+    fma = bool(getattr(flavor, "fma", False))
+    if not orclib.ref_available(1, "fw", fma): pytest.skip("needs the firmware build under oracle/_ref")
+    fs, B, blocks, S = 48000, 48, 12, 6
+    slots = {0: Oracle(1, x86_casts=True).save_slot(0)}
+    dump = W.flash_dump(W.flash_directory(default_slot=0, last_active_slot=0, slot_occupied=1), slots)
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    d = Dspi(flavor, S, device=0, populated_flash=True); assert d.set_rate(fs) == 0; d.set_volume(-6 * 256)
+    muted = Dspi(flavor, S, device=0); assert muted.set_rate(fs) == 0; muted.set_volume(-6 * 256)
+    pairs, sub, peaks = d.process_host(pcm, blocks, B)
+    mp, _, _ = muted.process_host(pcm, blocks, B)
+    assert not np.array_equal(mp, pairs)      # the default context fades into its first-boot mute, the flagged one does not
+    for s in (0, S - 1):
+        fw = Oracle(1, ref="fw", flash=dump, fma=fma); assert fw.set_rate(fs) == 0; fw.set_volume(-6 * 256)
+        assert fw.collect_bulk() == d.collect_bulk(s)
+        fp, fsub, fk, _ = fw.process(pcm[s], blocks, B)
+        assert np.array_equal(fp, pairs[s]) and np.array_equal(fsub, sub[s]) and np.array_equal(fk, peaks[s]), s
+        fw.close()
+    d.close(); muted.close()
+
+
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_flash_dump_boots_device_context(flavor):
     """SURVEY 8f-4 on the GPU: dspi_load_flash_dump on a DEVICE context (v2 directory, v1 directory, corrupt selected slot -> factory
