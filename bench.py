@@ -224,7 +224,7 @@ def latest_profile(kernel_key, contract, layout):
         if t.get("kernel_key", "chain3") != kernel_key or t.get("contract", "canonical") != contract or t.get("out_layout", "stream") != layout:
             continue
         if t.get("hbm_bytes_per_launch") and t.get("frames_per_launch"):
-            best = dict(source=os.path.basename(tpath), hbm_bytes_per_frame=t["hbm_bytes_per_launch"] / float(t["frames_per_launch"]),
+            best = dict(source=os.path.basename(tpath), src_sha16=t.get("src_sha16"), hbm_bytes_per_frame=t["hbm_bytes_per_launch"] / float(t["frames_per_launch"]),
                         valu_insts_per_frame=(t["valu_insts_per_launch"] / float(t["frames_per_launch"])) if t.get("valu_insts_per_launch") else None)
     return best
 
@@ -390,6 +390,8 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
     if rank != 0:
         return None
 
+    from dspi_amd.host import source_fingerprint
+    SRC_SHA16 = source_fingerprint()
     full_b, span_b = algorithmic_bytes(w, frames)
     kernel_key = {"3": "chain3", "2": "chain2", "2b": "chain2b", "5": "chain5", "perstream": "perstream", "perstream_eq": "perstream_eq"}[args.config]
 
@@ -402,6 +404,9 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
              "frac_launch_span": per_launch_frames * span_b / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
              "kernel_ms": m["kernel_ms"], "frames_per_launch": per_launch_frames,
              "traffic": prof["hbm_bytes_per_frame"] * per_launch_frames if prof else None, "traffic_source": prof["source"] if prof else None,
+             # the counters cannot be collected inside the timed run: they come from the committed profile of this variant, and that profile
+             # names the sources it was taken from — a different tree means the figure may describe an older kernel
+             "traffic_stale": (prof.get("src_sha16") != SRC_SHA16) if prof else None,
              "hbm_fraction_measured_traffic": (prof["hbm_bytes_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof else None,
              "valu_fraction": (prof["valu_insts_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS) if prof and prof["valu_insts_per_frame"] else None,
              "binds": "valu"}

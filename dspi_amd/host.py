@@ -35,6 +35,19 @@ class _Out(C.Structure):
 _lib = None
 
 
+def source_fingerprint(pkg_root: Path | None = None) -> str:
+    """sha256 (first 16 hex digits) over the library's sources (dspi_amd/csrc/*.hip *.inc *.h *.cpp, include/*.h), in name order.
+    tools/prof_summary.py stores it with every counter profile and bench.py compares it with the tree it runs from, so that a
+    roofline.traffic figure taken from an older build says so (traffic_stale)."""
+    import hashlib
+    root = Path(pkg_root) if pkg_root else Path(__file__).resolve().parent
+    files = sorted([p for pat in ("*.hip", "*.inc", "*.h", "*.cpp") for p in (root / "csrc").glob(pat)] + list((root.parent / "include").glob("*.h")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.name.encode()); h.update(b"\0"); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is not None:

@@ -55,3 +55,20 @@ def test_synthetic_mix_classes():
     assert not shifted[2].any()                                                       # classes follow the GLOBAL stream index (shards)
     noise = bench.synth_device(torch, torch.device("cpu"), S, frames, fs, 7, False).numpy()
     assert noise[18].any()
+
+
+def test_source_fingerprint_tracks_the_kernel_sources(tmp_path):
+    """Counter profiles carry the fingerprint of the sources they were taken from (tools/prof_summary.py); bench.py marks
+    roofline.traffic stale when the tree it runs from has another one."""
+    from dspi_amd import host
+    a = host.source_fingerprint()
+    assert len(a) == 16 and a == host.source_fingerprint()
+    pkg = tmp_path / "pkg"; (pkg / "csrc").mkdir(parents=True); (tmp_path / "include").mkdir()
+    (pkg / "csrc" / "k.hip").write_text("kernel"); (tmp_path / "include" / "api.h").write_text("api")
+    f0 = host.source_fingerprint(pkg)
+    (pkg / "csrc" / "k.hip").write_text("kernel, edited")
+    f1 = host.source_fingerprint(pkg)
+    (tmp_path / "include" / "api.h").write_text("api v2")
+    assert len({f0, f1, host.source_fingerprint(pkg), a}) == 4
+    p = bench.latest_profile("chain3", "fma", "stream")
+    if p is not None: assert "src_sha16" in p

@@ -67,6 +67,14 @@ if counters:
         lines.append(f"- HBM traffic (2 x FETCH + WRITE) = {tot / 1e9:.3f} GB/launch = {tot / frames:.1f} B/frame (algorithmic: {ALGO_BYTES:g} B/frame = {ALGO_BYTES * frames / 1e9:.3f} GB/launch)")
         if kernel_avg_us:
             lines.append(f"- at {kernel_avg_us:.0f} us/launch: {tot / kernel_avg_us / 1e6:.3f} TB/s moved, {ALGO_BYTES * frames / kernel_avg_us / 1e6:.3f} TB/s algorithmic")
+        try:      # which sources the profiled library was built from (bench.py flags a profile of another tree as stale)
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from dspi_amd.host import source_fingerprint, LIB_PATH
+            import hashlib
+            hb["src_sha16"] = source_fingerprint()
+            hb["lib_sha16"] = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
+        except Exception as e:
+            hb["src_sha16"] = None; hb["fingerprint_error"] = str(e)
         hb["hbm_bytes_per_launch"] = tot
         hb["frames_per_launch"] = frames
         hb["out_layout"] = os.environ.get("OUT_LAYOUT", "tiled")
