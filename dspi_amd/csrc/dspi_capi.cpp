@@ -63,7 +63,7 @@ struct dspi_ctx {
     // float flavour, per-lane VALUES: a row whose streams carry several presets of one structure runs the packed kernel with
     // its numbers in a value tile (dspi_image.h); ImageSig = what has to agree for that
     struct ImageSig {
-        uint32_t flags, ch_bypassed, out_enabled, out_mute, fs_hz, mute_transition, mix_nz;
+        uint32_t flags, ch_bypassed, out_enabled, out_mute, fs_hz, mute_transition, mix_nz, i2s_pairs;
         int32_t delay[kMaxOut];
         uint8_t kinds[kPvBandSlots];
     };
@@ -258,7 +258,7 @@ dspi_ctx::ImageSig make_sig(const DevImage &img) {
     dspi_ctx::ImageSig g;
     memset(&g, 0, sizeof g);
     g.flags = img.flags; g.ch_bypassed = img.ch_bypassed; g.out_enabled = img.out_enabled; g.out_mute = img.out_mute;
-    g.fs_hz = img.fs_hz; g.mute_transition = img.mute_transition;
+    g.fs_hz = img.fs_hz; g.mute_transition = img.mute_transition; g.i2s_pairs = img.i2s_pairs;
     for (int o = 0; o < kMaxOut; o++) {
         g.delay[o] = img.delay_samples[o];
         if (img.mix[0][o].f != 0.0f) g.mix_nz |= 1u << o;
@@ -903,6 +903,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.tiled_out = tiled ? 1u : 0u;
     a.fma = c->fma ? 1u : 0u;
     a.skip_silent = (flags & DSPI_OUT_ENABLED_ONLY) ? 1u : 0u;
+    a.i2s_slots = (flags & DSPI_OUT_I2S_SLOTS) ? 1u : 0u;
     if (c->flavor && !tiled && (out->pairs || out->sub)) {      // stream-major words of the packed kernel go through its exchange area
         const size_t xb = (size_t)c->n_wg * 2 * kMaxOut * kChunk * c->sm.row * 4;
         if ((rc = ensure(c, c->d_xwords, c->d_xwords_cap, xb))) return rc;

@@ -68,7 +68,8 @@ struct DevImage {
     int32_t lv_alpha_rms_q28;        // (int32)(alpha_rms * 2^28)  (leveller.c:286)
     // crossfeed (crossfeed.h:45-59)
     Word xf_lp_a0, xf_lp_b1, xf_ap_a;
-    uint32_t pad_[3];
+    uint32_t i2s_pairs;              // bit p: output slot p is an I2S slot (output_types[p] == 1, config.h:286-287); read with DSPI_OUT_I2S_SLOTS
+    uint32_t pad_[2];
 };
 
 // ------------------------------------------------------------------------------------------

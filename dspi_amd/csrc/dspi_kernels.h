@@ -25,6 +25,7 @@ struct KArgs {
     uint32_t *xwords;        // packed float kernel, stream-major output: exchange area [n_wg][2][kMaxOut][kChunk][128] words (or null: scattered stores)
     const float *vals;       // packed float kernel, per-lane values: value tiles [n_wg][kPvTileFloats] (dspi_image.h) or null
     uint32_t skip_silent;    // DSPI_OUT_ENABLED_ONLY: sample words of silent outputs (a disabled S/PDIF pair, the sub while it is off) need not be stored
+    uint32_t i2s_slots;      // DSPI_OUT_I2S_SLOTS: pairs whose slot is an I2S slot (DevImage::i2s_pairs) carry left-justified I2S words (word << 8)
     uint32_t fma;            // float flavour: the context's contract is DSPI_FLOAT_CONTRACT_FMA (selects the kernel family at launch)
 };
 

@@ -675,6 +675,7 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, const DevImage *
                 if (TAIL && i >= n) break;
                 float d = fmaxf(-1.0f, fminf(1.0f, x[i]));
                 wv[i] = pair_dead ? 0 : (int32_t)(d * 8388607.0f);
+                if (a.i2s_slots && ((img->i2s_pairs >> (o >> 1)) & 1u)) wv[i] = (int32_t)((uint32_t)wv[i] << 8);      // I2S slot (audio_i2s_multi.c:217-226)
             }
             const int pair = o >> 1, side = o & 1;
             const bool partner_here = side ? (j >= 1) : (j + 1 < o_count && o + 1 < N - 1);
@@ -1113,6 +1114,7 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const S
                 int32_t v = wadd(x[i], 1 << 5) >> 6;                                      // (x + 32) >> 6
                 v = v > 0x7FFFFF ? 0x7FFFFF : (v < -0x800000 ? -0x800000 : v);            // clip_s24
                 wv[i] = pair_dead ? 0 : v;
+                if (a.i2s_slots && ((img->i2s_pairs >> (o >> 1)) & 1u)) wv[i] = (int32_t)((uint32_t)wv[i] << 8);      // I2S slot (audio_i2s_multi.c:217-226)
             }
             const int pair = o >> 1, side = o & 1;
             const bool partner_here = side ? (j >= 1) : (j + 1 < o_count && o + 1 < N - 1);

@@ -1235,6 +1235,7 @@ void Params::build_image(DevImage &img) const {
     img.lv_gate_db = lv_gate_db; img.lv_max_gain_db = lv_max_gain_db;
     img.lv_alpha_rms_q28 = f2i_sat(lv_alpha_rms * (float)(1 << 28));
     img.xf_lp_a0 = xf_lp_a0; img.xf_lp_b1 = xf_lp_b1; img.xf_ap_a = xf_ap_a;
+    for (int i = 0; i < n_pairs; i++) if (output_types[i] == 1) img.i2s_pairs |= 1u << i;
 }
 
 }  // namespace dspi

@@ -18,6 +18,7 @@ ALL = -1
 MEM_DEVICE = 0x1
 OUT_TILED = 0x2
 OUT_ENABLED_ONLY = 0x4
+OUT_I2S_SLOTS = 0x8
 E_NODEVICE = -11
 E_UNSUPPORTED = -14
 
@@ -209,7 +210,7 @@ class Dspi:
         return int(self.L.dspi_tile_streams(self.h))
 
     def process_host(self, pcm: np.ndarray, n_blocks: int, block_len: int, bit_depth: int = 16,
-                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False, out=None, enabled_only=False):
+                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False, out=None, enabled_only=False, i2s_slots=False):
         """Host-memory convenience path (tests): pcm = int16 [streams][frames][2] or uint8 [streams][frames*6].
         Returns (pairs [S][P][F][2], sub [S][F], peaks [S][blocks][C]); with tiled=True the sample words come back in
         the DSPI_OUT_TILED layout: pairs [tiles][outputs][F][R], sub [tiles][F][R] (see untile())."""
@@ -228,7 +229,7 @@ class Dspi:
             sub = np.zeros((S, F), dtype=np.int32) if want_sub else None
         peaks = np.zeros((S, n_blocks, self.C), dtype=np.uint16) if want_peaks else None
         out = _Out(pairs.ctypes.data if want_pairs else None, sub.ctypes.data if want_sub else None, peaks.ctypes.data if want_peaks else None)
-        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0)), "process")
+        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0)), "process")
         return pairs, sub, peaks
 
     def untile(self, pairs_t: np.ndarray, sub_t: np.ndarray):
@@ -244,10 +245,10 @@ class Dspi:
         return pairs, sub
 
     def process_device(self, pcm_ptr: int, n_blocks: int, block_len: int, bit_depth: int = 16,
-                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0, tiled: bool = False, enabled_only: bool = False):
+                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0, tiled: bool = False, enabled_only: bool = False, i2s_slots: bool = False):
         """Zero-copy path: raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous, see sync()."""
         out = _Out(pairs_ptr or None, sub_ptr or None, peaks_ptr or None)
-        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE | (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0)), "process")
+        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE | (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0)), "process")
 
     def pdm_host(self, sub: np.ndarray, tiled: bool = False) -> np.ndarray:
         """PDM sub output (dspi_pdm_modulate) on host arrays: sub int32 [streams][frames] -> uint32 [streams][frames][8];

@@ -43,7 +43,7 @@ extern "C" {
 
 #define DSPI_ABI_VERSION 5   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
                               * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1,
-                              * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, DSPI_BOOT_POPULATED_FLASH, dspi_debug_launch_plan counts[5]
+                              * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, DSPI_OUT_I2S_SLOTS, DSPI_BOOT_POPULATED_FLASH, dspi_debug_launch_plan counts[5]
                               * (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
@@ -84,6 +84,10 @@ extern "C" {
 /* dspi_process flags */
 #define DSPI_MEM_DEVICE 0x1u       /* pcm_in and every pointer in dspi_out are device pointers (zero-copy) */
 #define DSPI_OUT_TILED 0x2u        /* pairs / sub use the device-native tiled layout described at dspi_out */
+#define DSPI_OUT_I2S_SLOTS 0x8u    /* pairs whose slot is an I2S slot in the stream's own parameters (output_types[], REQ_SET_OUTPUT_TYPE 0xC0) are written as
+                                    * the words the I2S driver shifts out — the S/PDIF producer word left-justified, word << 8
+                                    * (pico_audio_i2s_multi/audio_i2s_multi.c:217-226) — instead of going through dspi_i2s_encode afterwards: the same
+                                    * words, without the second pass over 64 bytes per frame.  S/PDIF-typed pairs are unaffected. */
 #define DSPI_OUT_ENABLED_ONLY 0x4u /* the caller does not read the sample words of SILENT outputs — an S/PDIF pair whose two outputs are
                                     * disabled (the firmware zero-fills it, usb_audio.c:930-933), the sub while it is disabled or Core 1
                                     * runs the EQ worker — so the library may leave those parts of pairs / sub unwritten instead of storing

@@ -651,6 +651,40 @@ def test_host_buffer_pipeline_chunks(flavor, tiled):
     dh.close(); dd.close()
 
 
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+@pytest.mark.parametrize("tiled", (False, True))
+def test_i2s_slot_words_fused_into_the_chain(flavor, tiled, monkeypatch):
+    """DSPI_OUT_I2S_SLOTS: the chain itself writes the left-justified words of the slots that are I2S slots (per stream: streams 3
+    and 70 switch another slot than everybody else, so the row takes the per-lane kernels) — the same words the two-call sequence
+    gives (dspi_process, then dspi_i2s_encode by type), which tests/test_gpu_parity.py::test_i2s_slot_words pins to the reference's
+    i2s_wrap_producer_give; also through the latency layout (float, a preset of its class)."""
+    fs, B, blocks = 48000, 48, 40            # (the boot mute and the type switch's pipeline mute take the first packets)
+    S = 140 if flavor else 75
+    n_pairs = 4 if flavor else 2
+    def setup(d, latency_class):
+        d.set_rate(fs); d.set_volume(-5 * 256)
+        assert d.load_bulk(_latency_blob() if latency_class else WL.full_chain_blob(int(flavor))) == 0
+        d.vendor_get(W.REQ["SET_OUTPUT_TYPE"], 1 | (1 << 8), cap=1, stream=-1)                    # slot 1 -> I2S, every stream (DSPI_ALL_STREAMS)
+        for s in (3, 70): d.vendor_get(W.REQ["SET_OUTPUT_TYPE"], 0 | (1 << 8), cap=1, stream=s)   # slot 0 too, two streams only
+    for latency_class in ((False, True) if flavor else (False,)):
+        if latency_class: monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+        pcm = WL.synth_pcm16(S, B * blocks, fs)
+        plain, fused = Dspi(flavor, S, device=0), Dspi(flavor, S, device=0)
+        setup(plain, latency_class); setup(fused, latency_class)
+        p0, s0, k0 = plain.process_host(pcm, blocks, B)
+        p1, s1, k1 = fused.process_host(pcm, blocks, B, tiled=tiled, i2s_slots=True)
+        if tiled: p1, s1 = fused.untile(p1, s1)
+        want = p0.copy()
+        for s in range(S):
+            mask = 0b10 | (0b01 if s in (3, 70) else 0)
+            for pr in range(n_pairs):
+                if mask & (1 << pr): want[s, pr] = (want[s, pr].astype(np.uint32) << np.uint32(8)).astype(np.int32)
+        assert np.array_equal(p1, want) and np.array_equal(s1, s0) and np.array_equal(k1, k0), latency_class
+        assert int(np.abs(p0[0, 1, -B:]).max()) > 0 and int(np.abs(p0[3, 0, -B:]).max()) > 0
+        if latency_class: assert fused.launch_plan()["latency_layout"] > 0
+        plain.close(); fused.close()
+
+
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
 def test_boot_from_populated_flash_has_no_first_boot_mute(flavor):
     """DSPI_BOOT_POPULATED_FLASH: a context of devices that do NOT boot for the first time starts unmuted — the default context arms the
