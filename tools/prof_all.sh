@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/prof_all.sh <round tag> — rocprofv3 trace + PMC summaries of every kernel the bench can drive (run via gpurun); the
 # summaries land in gpurun_out/profsum/ and are copied to profiles/ by hand.
-R=${1:-r02}
+R=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 run() { # tag, bench args, env...
   local tag=$1 args=$2; shift 2
@@ -14,7 +14,8 @@ run c "--contract canonical --out-layout tiled" CONTRACT=canonical OUT_LAYOUT=ti
 run d "--contract canonical --out-layout stream" CONTRACT=canonical OUT_LAYOUT=stream KERNEL_KEY=chain3 NOTE="config 3, canonical contract, stream-major words"
 run e "--config 5" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=chain5 STREAMS=16384 BLOCK_LEN=48 ALGO_BYTES=56 KERNEL_LIKE="%chain_kernel<0%" NOTE="config 5: Q28 7-channel chain, 16 384 streams, 48 kHz"
 run k "--config 5 --streams 65536" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=chain5_64k STREAMS=65536 BLOCK_LEN=48 ALGO_BYTES=56 KERNEL_LIKE="%chain_kernel<0%" NOTE="Q28 7-channel chain at 65 536 streams (two workgroups per CU)"
-run l "--config 2" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain2 STREAMS=4096 BLOCK_LEN=48 PACKETS_PER_LAUNCH=2000 ALGO_BYTES=12 KERNEL_LIKE="%chain_kernel_pk%" NOTE="BASELINE config 2: 4 096 streams, master PEQ only, 2 000 packets per launch"
+run l "--config 2" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain2 STREAMS=4096 BLOCK_LEN=48 PACKETS_PER_LAUNCH=2000 ALGO_BYTES=12 KERNEL_LIKE="%chain_kernel_skew%" NOTE="BASELINE config 2: 4 096 streams, master PEQ only, 2 000 packets per launch — the latency layout (dspi_chain_skew.inc), DSPI_OUT_ENABLED_ONLY"
+run m "--config 2" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain2_packed STREAMS=4096 BLOCK_LEN=48 PACKETS_PER_LAUNCH=2000 ALGO_BYTES=12 KERNEL_LIKE="%chain_kernel_pk%" DSPI_F32_LAYOUT=packed NOTE="BASELINE config 2 forced onto the packed kernel (DSPI_F32_LAYOUT=packed): the round-2 path, for comparison"
 run f "--config perstream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=perstream KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets with identical filters (preamp per stream): packed kernel, per-lane values, shared band coefficients; stream-major words"
 run i "--config perstream_eq --out-layout tiled" CONTRACT=fma OUT_LAYOUT=tiled KERNEL_KEY=perstream_eq KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets whose filters differ: packed kernel, every band coefficient per lane from the value tiles; tiled words"
 run j "--config i2s --out-layout stream" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=i2s PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=64 KERNEL_LIKE="%i2s%" NOTE="I2S slot words, 65 536 streams x 4 pairs x 2 400 frames"
