@@ -659,13 +659,14 @@ def test_i2s_slot_words_fused_into_the_chain(flavor, tiled, monkeypatch):
     gives (dspi_process, then dspi_i2s_encode by type), which tests/test_gpu_parity.py::test_i2s_slot_words pins to the reference's
     i2s_wrap_producer_give; also through the latency layout (float, a preset of its class)."""
     fs, B, blocks = 48000, 48, 40            # (the boot mute and the type switch's pipeline mute take the first packets)
-    S = 140 if flavor else 75
+    S = 300 if flavor else 75                # (float: a third row whose presets differ in a number only — the packed per-lane-value kernel)
     n_pairs = 4 if flavor else 2
     def setup(d, latency_class):
         d.set_rate(fs); d.set_volume(-5 * 256)
         assert d.load_bulk(_latency_blob() if latency_class else WL.full_chain_blob(int(flavor))) == 0
         d.vendor_get(W.REQ["SET_OUTPUT_TYPE"], 1 | (1 << 8), cap=1, stream=-1)                    # slot 1 -> I2S, every stream (DSPI_ALL_STREAMS)
         for s in (3, 70): d.vendor_get(W.REQ["SET_OUTPUT_TYPE"], 0 | (1 << 8), cap=1, stream=s)   # slot 0 too, two streams only
+        if flavor and not latency_class: d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -7.5), stream=270)
     for latency_class in ((False, True) if flavor else (False,)):
         if latency_class: monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
         pcm = WL.synth_pcm16(S, B * blocks, fs)
@@ -682,6 +683,7 @@ def test_i2s_slot_words_fused_into_the_chain(flavor, tiled, monkeypatch):
         assert np.array_equal(p1, want) and np.array_equal(s1, s0) and np.array_equal(k1, k0), latency_class
         assert int(np.abs(p0[0, 1, -B:]).max()) > 0 and int(np.abs(p0[3, 0, -B:]).max()) > 0
         if latency_class: assert fused.launch_plan()["latency_layout"] > 0
+        elif flavor: assert fused.launch_plan()["packed_per_lane_values"] > 0
         plain.close(); fused.close()
 
 

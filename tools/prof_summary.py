@@ -26,7 +26,7 @@ if os.path.exists(tr):
     q = "select name, vgpr_count, sgpr_count, lds_size, scratch_size, workgroup_x, grid_x from kernels where name like '" + KERNEL_LIKE + "' limit 1"
     try:
         for r in db.execute(q):
-            lines += ["", f"chain kernel resources: VGPR {r[1]}, SGPR {r[2]}, LDS {r[3]} B/workgroup, scratch {r[4]} B/lane, workgroup {r[5]}, grid {r[6]}"]
+            lines += ["", f"chain kernel resources: VGPR {r[1]} as rocprofv3 reports it (= half the allocation: hipcc's resource remark, tools/regs.sh, says {2 * r[1]}), SGPR {r[2]}, LDS {r[3]} B/workgroup, scratch {r[4]} B/lane, workgroup {r[5]}, grid {r[6]}"]
     except Exception as e:
         lines.append(f"(resource query failed: {e})")
 counters = {}
