@@ -245,6 +245,7 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ unsigned long long g_wave_timing[36 + 48];   // [36 + 4*rank + k]: phase timers of the packed output waves   // [2w] busy, [2w+1] total, [24+w] HW_ID of wave w of workgroup 0
 #define WT_PHASE(r, k, t) do { if (lane == 0) atomicAdd(&g_wave_timing[36 + 4 * (r) + (k)], (unsigned long long)(t)); } while (0)
 #define WT_NOW() __builtin_amdgcn_s_memtime()
+#define WT_COUNT(k, lo) do { if ((lo) == 0) atomicAdd(&g_wave_timing[36 + (k)], 1ull); } while (0)      // slots of the unused phase timers of ranks 0-2
 #define WT_DECL unsigned long long wt_busy = 0, wt_t0 = __builtin_amdgcn_s_memtime(), wt_start = wt_t0
 #define WT_BEFORE_BARRIER wt_busy += __builtin_amdgcn_s_memtime() - wt_t0
 #define WT_AFTER_BARRIER wt_t0 = __builtin_amdgcn_s_memtime()
@@ -253,6 +254,7 @@ __device__ unsigned long long g_wave_timing[36 + 48];   // [36 + 4*rank + k]: ph
 #else
 #define WT_PHASE(r, k, t)
 #define WT_NOW() 0ull
+#define WT_COUNT(k, lo)
 #define WT_DECL
 #define WT_BEFORE_BARRIER
 #define WT_AFTER_BARRIER
@@ -1503,7 +1505,7 @@ __global__ void state_init_kernel(uint32_t *state, uint32_t n_wg) {
 size_t chain_lds_bytes(int flavor, int packed) {
     const StateMap sm = make_state_map(flavor);
     // Q28 one-stream kernel: + queued gain decisions, the posted right-channel envelope and the role table (kQ28Mail + 2 + 1 rows)
-    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox + 2 : (flavor ? 0 : 7))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);      // packed: + role table (16 B) and the posted left envelope (2 rows)
+    return (size_t)(sm.lds_slots + sm.n_ch + 2 * 2 * T + (packed ? kMailbox + 4 : (flavor ? 0 : 7))) * (packed ? ROWP : (uint32_t)kLanes) * sizeof(uint32_t) + (packed ? 16 : 0);      // packed: + role table (16 B) and the posted left / right envelopes (2 x 2 rows)
 }
 
 #endif
