@@ -44,7 +44,7 @@ def run(label, blob, outputs=True, steps=4):
     if os.environ.get('DSPI_LIB', '').endswith('timing.so'):
         extra += '\n      output phases Mcyc (eq / wait dl / emit / dl store): ' + ' '.join('o%d:' % o + '/'.join(f'{buf[36 + 4 * (3 + o) + k] / nwg / (steps + 1) / 1e6:.2f}' for k in range(4)) for o in range(9))
     if os.environ.get('DSPI_LIB', '').endswith('timing.so'):
-        extra += '\n      delay / ring row accesses per launch (fast / per-stream path): loads %d / %d, stores %d / %d, other-wave loads %d / %d' % tuple(buf[36 + k] // (steps + 1) for k in (0, 1, 2, 3, 4, 5)) + '; sites 6-11: ' + ' '.join(str(buf[36 + k] // (steps + 1)) for k in range(6, 12))
+        extra += '\n      delay / ring row accesses per launch (fast / per-stream path): loads %d / %d, stores %d / %d, other-wave loads %d / %d' % tuple(buf[36 + k] // (steps + 1) for k in (0, 1, 2, 3, 4, 5))
     print(f'{label:44s} {dt * 1e3:8.2f} ms/step  {S * NB * B / dt / 1e9:7.2f} Gframes/s{extra}', flush=True)
     d.close()
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+# tools/pmc_vmem.sh — vector-memory instruction counts (SQ_INSTS_VMEM_RD / _WR / FLAT, SMEM, LDS) per launch of the packed chain kernel for the
+# per-stream-preset workloads next to the shared preset (run via gpurun); how the spills of the per-lane-filter kernel were found
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 run() { tag=$1; shift
   rm -rf /tmp/pv_$tag; timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_INSTS_LDS -d /tmp/pv_$tag -o pmc -- env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants $ARGS > /tmp/pv_$tag.log 2>&1
