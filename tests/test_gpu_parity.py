@@ -615,6 +615,43 @@ def test_full_size_stream_major_groups_agree(flavor, fs, B, blocks):
     d.close()
 
 
+@pytest.mark.parametrize("two_b", (False, True), ids=("config2", "config2b"))
+def test_full_size_config2_latency_layout(two_b):
+    """BASELINE config 2 at the size bench.py --config 2 times it: 4 096 streams (one workgroup of eight stream pairs on every CU), 48-frame
+    packets, the firmware contract, DSPI_OUT_ENABLED_ONLY — taken to the latency layout by the library's own size rule (nothing forced),
+    three launches of 200 packets.  Every workgroup (16 streams) gets the same input: all must produce workgroup 0's live words and
+    peaks, the silent pairs and the sub must stay unwritten, and workgroup 0 is checked against the oracle over all three launches."""
+    import torch
+    fs, B, blocks, calls, S, R = 48000, 48, 200, 3, 4096, 16
+    blob = WL.config2_blob(two_b)
+    d = Dspi(W.F32_FMA, S, device=0); d.set_rate(fs); d.set_volume(-10 * 256); assert d.load_bulk(blob) == 0
+    base = WL.synth_pcm16(R, B * blocks * calls, fs)
+    dev = torch.device("cuda", 0)
+    groups, frames = S // R, B * blocks
+    pairs = torch.empty((S, 4, frames, 2), dtype=torch.int32, device=dev); sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
+    peaks = torch.empty((S, blocks, 11), dtype=torch.int16, device=dev)
+    got = []
+    for c in range(calls):
+        part = torch.from_numpy(np.ascontiguousarray(base[:, c * frames:(c + 1) * frames])).to(dev)
+        pcm = part.repeat(groups, 1, 1).contiguous()
+        pairs.fill_(0x55555555); sub.fill_(0x55555555)
+        torch.cuda.synchronize()
+        d.process_device(pcm.data_ptr(), blocks, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), enabled_only=True); d.sync()
+        plan = d.launch_plan()
+        assert plan["latency_layout"] == S // 128 and plan["packed_shared"] == 0, plan      # (work items are rows of 128 streams: eight workgroups each)
+        pv, kv = pairs.view(groups, R, 4, frames, 2), peaks.view(groups, R, blocks, 11)
+        assert bool((pv[:, :, 0] == pv[0:1, :, 0]).all()), f"launch {c}: a workgroup's words differ from workgroup 0"
+        assert bool((kv == kv[0:1]).all()), f"launch {c}: a workgroup's peaks differ from workgroup 0"
+        assert bool((pairs[:, 1:] == 0x55555555).all()) and bool((sub == 0x55555555).all()), f"launch {c}: a silent output was written"
+        got.append((pairs[:R, 0].cpu().numpy().copy(), peaks[:R].cpu().numpy().view(np.uint16).copy()))
+    p0 = np.concatenate([g[0] for g in got], axis=1); k0 = np.concatenate([g[1] for g in got], axis=1)
+    for s in (0, 1, 7, 8, R - 1):
+        (rp, rs, rk, _), _ = oracle_run(W.F32_FMA, fs, -10 * 256, blob, base[s], blocks * calls, B, 16)
+        assert np.array_equal(rp[0], p0[s]) and np.array_equal(rk, k0[s]), s
+        assert int(np.abs(rp[1:]).max()) == 0 and int(np.abs(rs).max()) == 0
+    d.close()
+
+
 @pytest.mark.parametrize("flavor,tiled", [(W.F32_FMA, False), (1, True), (0, False), (0, True)])
 def test_host_buffer_pipeline_chunks(flavor, tiled):
     """dspi_process on HOST buffers large enough to take the chunked pipeline (rows cut into chunks, H2D / kernels / D2H of consecutive
