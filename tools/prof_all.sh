@@ -17,7 +17,9 @@ run k "--config 5 --streams 65536" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY
 run l "--config 2" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain2 STREAMS=4096 BLOCK_LEN=48 PACKETS_PER_LAUNCH=2000 ALGO_BYTES=12 KERNEL_LIKE="%chain_kernel_skew%" NOTE="BASELINE config 2: 4 096 streams, master PEQ only, 2 000 packets per launch — the latency layout (dspi_chain_skew.inc), DSPI_OUT_ENABLED_ONLY"
 run m "--config 2" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain2_packed STREAMS=4096 BLOCK_LEN=48 PACKETS_PER_LAUNCH=2000 ALGO_BYTES=12 KERNEL_LIKE="%chain_kernel_pk%" DSPI_F32_LAYOUT=packed NOTE="BASELINE config 2 forced onto the packed kernel (DSPI_F32_LAYOUT=packed): the round-2 path, for comparison"
 run f "--config perstream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=perstream KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets with identical filters (preamp per stream): packed kernel, per-lane values, shared band coefficients; stream-major words"
-run i "--config perstream_eq --out-layout tiled" CONTRACT=fma OUT_LAYOUT=tiled KERNEL_KEY=perstream_eq KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets whose filters differ: packed kernel, every band coefficient per lane from the value tiles; tiled words"
+run i "--config perstream_eq --out-layout tiled" CONTRACT=fma OUT_LAYOUT=tiled KERNEL_KEY=perstream_eq KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets, one master band differs per stream: packed kernel, the master channels' band coefficients per lane from the value tiles; tiled words"
+run n "--config perstream_eq --out-layout tiled" CONTRACT=fma OUT_LAYOUT=tiled KERNEL_KEY=perstream_eq_all KERNEL_LIKE="%chain_kernel_pk%" DSPI_DEBUG=1 NOTE="65 536 distinct presets, EVERY band of every channel differs per stream (DSPI_DEBUG=1): the worst case of the per-lane-filter kernel; tiled words"
+run o "--config perstream_eq" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=perstream_eq KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets, one master band differs per stream; stream-major words"
 run j "--config i2s --out-layout stream" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=i2s PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=64 KERNEL_LIKE="%i2s%" NOTE="I2S slot words, 65 536 streams x 4 pairs x 2 400 frames"
 run g "--config pdm --out-layout tiled" CONTRACT=integer OUT_LAYOUT=tiled KERNEL_KEY=pdm PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=36 KERNEL_LIKE="%pdm_kernel%" NOTE="PDM sigma-delta modulator, 65 536 streams x 2 400 samples (frames = sub samples)"
 run h "--config spdif --out-layout stream" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=spdif PACKETS_PER_LAUNCH=25 BLOCK_LEN=96 ALGO_BYTES=96 KERNEL_LIKE="%spdif%" NOTE="S/PDIF subframe encoder, 65 536 streams x 4 pairs x 2 400 frames"
