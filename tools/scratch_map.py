@@ -6,7 +6,7 @@ memory traffic per wave and step (per-lane filters).
 Compiles dspi_amd/csrc/dspi_kernels.hip for that part to assembly (/tmp/scratch_map_p<part>.s; reused when newer than the sources)."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-part, targs = sys.argv[1], sys.argv[2]
+part, targs = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "all")      # "all": one line per instance of the part
 src = os.path.join(ROOT, "dspi_amd", "csrc")
 out = f"/tmp/scratch_map_p{part}.s"
 newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".hip", ".inc", ".h")))
@@ -15,6 +15,16 @@ if not os.path.exists(out) or os.path.getmtime(out) < newest:
                            "-fno-slp-vectorize", "-fPIC", f"-DDSPI_PART={part}", "--cuda-device-only", "-S", os.path.join(src, "dspi_kernels.hip"), "-o", out],
                           stderr=subprocess.DEVNULL)
 T = open(out).read().split("\n")
+if targs == "all":
+    import itertools
+    names = sorted({l.split(":")[0] for l in T if l.startswith("_Z") and "chain_kernel_pkI" in l and ":" in l})
+    for nm in names:
+        bits = re.search(r"chain_kernel_pkI((?:Lb[01]E)+)", nm).group(1)
+        ta = ", ".join("true" if b == "1" else "false" for b in re.findall(r"Lb([01])E", bits))
+        r = subprocess.run([sys.executable, __file__, part, ta], capture_output=True, text=True).stdout.strip().split("\n")
+        tot = sum(int(m.group(1)) + int(m.group(2)) for l in r[1:] for m in [re.search(r": (\d+) scratch loads \+ (\d+) stores", l)] if m)
+        print(f"<{ta}>  in-loop scratch instructions per step, all roles: {tot}   " + "; ".join(re.sub(r"time loop lines \S+ \(", "(", l.strip()).split(" per step")[0] for l in r[1:] if not " 0 scratch loads + 0 stores" in l))
+    sys.exit(0)
 mangled = "chain_kernel_pkI" + "".join("Lb%dE" % (a.strip() == "true") for a in targs.split(","))
 starts = [i for i, l in enumerate(T) if l.startswith("_Z") and mangled in l.split(":")[0] and ":" in l]
 if not starts: sys.exit("no kernel " + mangled)
