@@ -46,8 +46,8 @@ struct dspi_ctx {
     std::vector<uint32_t> image_item_offset[4];
     // chain launches: the same work lists concatenated over images, grouped by what the kernels are specialised on
     // (float: leveller on/off), so a dspi_process is a handful of launches however many presets are in play
-    std::vector<WgItem> launch_items[2][6];      // [leveller off / on][list]; list 5: the latency layout (dspi_chain_skew.inc)
-    uint32_t launch_item_offset[2][6] = {};
+    std::vector<WgItem> launch_items[2][7];      // [leveller off / on][list]; lists 5, 6: the latency layout (dspi_chain_skew.inc) without / with output rows
+    uint32_t launch_item_offset[2][7] = {};
     WgItem *d_litems = nullptr; size_t d_litems_cap = 0;
     uint32_t *d_stream_image = nullptr; size_t d_stream_image_cap = 0;   // image index per stream (per-lane parameter kernel)
     bool launch_dirty = true;
@@ -269,24 +269,27 @@ dspi_ctx::ImageSig make_sig(const DevImage &img) {
     return g;
 }
 
-// The latency layout of the float chain (dspi_chain_skew.inc) serves images with the leveller off whose outputs run no EQ (disabled,
-// muted, every band flat, or the sub in EQ-worker mode: exactly the cases in which output_item_pk skips the band loops).
-bool skew_eligible(const dspi_ctx::ImageSig &g) {
-    if (g.flags & IF_LEVELLER_ON) return false;
+// The latency layout of the float chain (dspi_chain_skew.inc) serves images with the leveller off.  Class 1: no output runs an EQ
+// (disabled, muted, every band flat, or the sub in EQ-worker mode: exactly the cases in which output_item_pk skips the band loops) —
+// eight stream pairs per workgroup, the outputs frame-parallel.  Class 2: some output does — two pairs per workgroup, every output a
+// systolic row of its own.  0: not served (leveller on: its two passes per packet need the ring hand-off).
+int skew_class(const dspi_ctx::ImageSig &g) {
+    if (g.flags & IF_LEVELLER_ON) return 0;
     for (int o = 0; o < kMaxOut; o++) {
         const bool enabled = (g.out_enabled >> o) & 1u, muted = (g.out_mute >> o) & 1u, flat = (g.ch_bypassed >> (2 + o)) & 1u;
         const bool processed = o != kMaxOut - 1 || (g.flags & IF_SUB_ACTIVE);
-        if (processed && enabled && !muted && !flat) return false;
+        if (processed && enabled && !muted && !flat) return 2;
     }
-    return true;
+    return 1;
 }
-// ... for launches that leave the chip underfilled: up to one of its eight-pair workgroups per CU (84 KB of LDS each); beyond that the
-// packed kernel's throughput layout wins (tools/probe/probe8.hip).  DSPI_F32_LAYOUT=skew|packed forces one (tests, development).
-uint32_t skew_pair_limit(int device) {
+// ... for launches that leave the chip underfilled: class 1 up to one of its eight-pair workgroups per CU (84 KB of LDS each), class 2
+// up to two of its two-pair workgroups per CU (79 KB each); beyond that the packed kernel's throughput layout wins
+// (tools/probe/probe8.hip, tools/bench_skew.py).  DSPI_F32_LAYOUT=skew|packed forces one (tests, development).
+uint32_t skew_pair_limit(int device, int cls) {
     if (const char *e = getenv("DSPI_F32_LAYOUT")) { if (!strcmp(e, "skew")) return 0xffffffffu; if (!strcmp(e, "packed")) return 0u; }
     int cus = 0;
     if (device < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-    return 8u * (uint32_t)cus;
+    return (cls == 2 ? 4u : 8u) * (uint32_t)cus;
 }
 
 dspi_ctx::BandHash hash_bands(const DevImage &img) {
@@ -334,7 +337,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
                 if (memcmp(ref->eq, cur->eq, sizeof ref->eq) != 0 || memcmp(ref->loud, cur->loud, sizeof ref->loud) != 0) c->row_pv[it.wg] = 1;
             }
     }
-    for (int lev = 0; lev < 2; lev++) c->launch_items[lev][5].clear();
+    for (int lev = 0; lev < 2; lev++) { c->launch_items[lev][5].clear(); c->launch_items[lev][6].clear(); }
     for (int lev = 0; lev < 2; lev++)
         for (int k = 0; k < 5; k++) {
             auto &v = c->launch_items[lev][k];
@@ -389,20 +392,25 @@ int rebuild_launch_lists(dspi_ctx *c) {
             // by row: a range of rows is then a contiguous run of every list (dspi_process stages host buffers row chunk by row chunk)
             std::stable_sort(v.begin(), v.end(), [](const WgItem &x, const WgItem &y) { return x.wg < y.wg; });
         }
-    // float, shared-preset lanes with the leveller off: those whose image suits the latency layout move to list 5 when the launch is
-    // small enough to leave the chip underfilled
+    // float, shared-preset lanes with the leveller off: those whose image suits the latency layout move to list 5 / 6 (by class) when
+    // the launch is small enough to leave the chip underfilled
     if (c->flavor && c->image_sig.size() >= c->images.size()) {
         auto &v = c->launch_items[0][1];
-        uint64_t pairs = 0;
-        for (const WgItem &it : v) if (skew_eligible(c->image_sig[it.image])) pairs += (uint64_t)__builtin_popcountll(it.mask);
-        if (pairs > 0 && pairs <= skew_pair_limit(c->device)) {
+        uint64_t pairs[3] = {0, 0, 0};
+        for (const WgItem &it : v) pairs[skew_class(c->image_sig[it.image])] += (uint64_t)__builtin_popcountll(it.mask);
+        bool take[3] = {false, false, false};
+        for (int cls = 1; cls <= 2; cls++) take[cls] = pairs[cls] > 0 && pairs[cls] <= skew_pair_limit(c->device, cls);
+        if (take[1] || take[2]) {
             std::vector<WgItem> keep;
-            for (const WgItem &it : v) (skew_eligible(c->image_sig[it.image]) ? c->launch_items[0][5] : keep).push_back(it);
+            for (const WgItem &it : v) {
+                const int cls = skew_class(c->image_sig[it.image]);
+                (take[cls] ? c->launch_items[0][4 + cls] : keep).push_back(it);
+            }
             v.swap(keep);
         }
     }
     for (int lev = 0; lev < 2; lev++)
-        for (int k = 0; k < 6; k++) {
+        for (int k = 0; k < 7; k++) {
             c->launch_item_offset[lev][k] = (uint32_t)total;
             total += c->launch_items[lev][k].size();
         }
@@ -411,7 +419,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
     if ((rc = ensure(c, c->d_stream_image, c->d_stream_image_cap, (size_t)c->n_streams * 4))) return rc;
     HIPCK(c, hipStreamSynchronize(c->hs));      // no launch may still be reading the lists we overwrite
     for (int lev = 0; lev < 2; lev++)
-        for (int k = 0; k < 6; k++)
+        for (int k = 0; k < 7; k++)
             if (!c->launch_items[lev][k].empty())
                 HIPCK(c, hipMemcpy(c->d_litems + c->launch_item_offset[lev][k], c->launch_items[lev][k].data(),
                                    c->launch_items[lev][k].size() * sizeof(WgItem), hipMemcpyHostToDevice));
@@ -743,6 +751,7 @@ int dspi_debug_launch_plan(dspi_ctx *c, uint32_t *counts, size_t n_counts) {
     if (!c || !counts || n_counts < 5) return DSPI_E_INVAL;
     const int n = n_counts >= 6 ? 6 : 5;      // [5]: items of the latency layout (dspi_chain_skew.inc)
     for (int k = 0; k < n; k++) counts[k] = (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size());
+    if (n == 6) counts[5] += (uint32_t)c->launch_items[0][6].size();      // both shapes of the latency layout
     if (c->flavor) counts[0] = 0;      // (list 0 of a float context is bookkeeping for the state mutations, never launched)
     return n;
 }
@@ -924,10 +933,10 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     // per-lane-parameter kernel for both lane components in one launch (list 2).  Q28: rows with one image run workgroup-uniform
     // (list 0), rows with several in per-lane-parameter mode (list 2).  A launch covers every image.
     struct Launch { int list; int packed; };
-    static const Launch kF32[] = {{1, 1}, {5, 5}, {3, 3}, {4, 4}, {2, 2}};      // lists 3 / 4: per-lane-value rows (packed kernel + value tiles); 5: latency layout
+    static const Launch kF32[] = {{1, 1}, {5, 5}, {6, 6}, {3, 3}, {4, 4}, {2, 2}};      // lists 3 / 4: per-lane-value rows (packed kernel + value tiles); 5 / 6: latency layout
     static const Launch kQ28[] = {{0, 0}, {2, 2}};
     const Launch *ls = c->flavor ? kF32 : kQ28;
-    const int nl = c->flavor ? 5 : 2;
+    const int nl = c->flavor ? 6 : 2;
     a.vals = c->d_vals;
     // the chain launches for the rows [r0, r1) (the lists are sorted by row)
     auto launch_rows = [&](uint32_t r0, uint32_t r1) -> int {

@@ -1620,26 +1620,30 @@ DSPI_PK_FAMILY(5, true, true, true)
 #endif
 
 // the latency layout of the float chain (dspi_chain_skew.inc): part 7
-hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, hipStream_t stream);
+hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, bool out_rows, hipStream_t stream);
 #if !defined(DSPI_PART) || DSPI_PART == 7
-hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, hipStream_t stream) {
-    const dim3 grid(n_items * (64 / kSkPairs)), block(64 * kSkWaves);
-    const size_t lds = sizeof(SkShared);
+template <bool EQO>
+static hipError_t launch_chain_skew_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    const dim3 grid(n_items * (64 / SkCfg<EQO>::pairs)), block(64 * kSkWaves);
+    const size_t lds = sizeof(SkShared<EQO>);
     static bool attr_set[kMaxDevices] = {};      // per device, see launch_chain_t
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
     if (!attr_set[dev] || dev == kMaxDevices - 1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<true, true, EQO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<true, false, EQO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<false, true, EQO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<false, false, EQO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
     const bool p24 = args.bit_depth == 24;
-    if (args.fma) { if (p24) hipLaunchKernelGGL((chain_kernel_skew<true, true>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<true, false>), grid, block, lds, stream, args); }
-    else { if (p24) hipLaunchKernelGGL((chain_kernel_skew<false, true>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<false, false>), grid, block, lds, stream, args); }
+    if (args.fma) { if (p24) hipLaunchKernelGGL((chain_kernel_skew<true, true, EQO>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<true, false, EQO>), grid, block, lds, stream, args); }
+    else { if (p24) hipLaunchKernelGGL((chain_kernel_skew<false, true, EQO>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<false, false, EQO>), grid, block, lds, stream, args); }
     return hipGetLastError();
+}
+hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, bool out_rows, hipStream_t stream) {
+    return out_rows ? launch_chain_skew_t<true>(args, n_items, stream) : launch_chain_skew_t<false>(args, n_items, stream);
 }
 #endif
 
@@ -1702,7 +1706,7 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
     // per-lane images (float always; Q28 rows with several presets)
     if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
     // float: the context's contract (DSPI_FLOAT_CONTRACT_FMA) picks the kernel family
-    if (packed == 5) return launch_chain_skew(args, n_items, stream);
+    if (packed == 5 || packed == 6) return launch_chain_skew(args, n_items, packed == 6, stream);
     if (packed != 1 && packed != 3 && packed != 4) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
     if (packed == 3) return args.fma ? launch_chain_pk_f5(args, leveller_on, n_items, stream) : launch_chain_pk_f2(args, leveller_on, n_items, stream);
     if (packed == 4) return args.fma ? launch_chain_pk_f4(args, leveller_on, n_items, stream) : launch_chain_pk_f1(args, leveller_on, n_items, stream);

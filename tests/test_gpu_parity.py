@@ -121,6 +121,36 @@ def test_latency_layout(flavor, fs, B, depth, monkeypatch):
     d.close()
 
 
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+@pytest.mark.parametrize("fs,B,depth", [(48000, 48, 16), (96000, 96, 24), (44100, 45, 16), (44100, 44, 24), (48000, 1, 16), (48000, 7, 16), (48000, 13, 16), (48000, 14, 16), (48000, 97, 16), (96000, 192, 16)])
+def test_latency_layout_output_rows(flavor, fs, B, depth, monkeypatch):
+    """The latency layout's second shape (dspi_chain_skew.inc, EQO): presets whose OUTPUTS run EQs — the full chain of BASELINE config 3
+    with the leveller off: loudness, master PEQ, crossfeed, 2 x 9 matrix, nine 10-band output EQs of every band form, gains, delays, the
+    sub.  Two stream pairs per workgroup, every output a systolic row a batch behind the master rows; every packet length class (shorter
+    than the extra lead of the master rows included), both input depths, a ragged stream count, three calls."""
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    blob = WL.full_chain_blob(1)
+    blob["leveller"]["enabled"] = 0
+    blocks = 24 if B >= 44 else 150
+    S = 11          # five pairs + a pair that holds one stream: three workgroups, the last one half filled
+    d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-7 * 256); assert d.load_bulk(blob) == 0
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm)
+    per = blocks // 3
+    unit = B if depth == 16 else B * 6
+    outs = [d.process_host(np.ascontiguousarray(data[:, c * per * unit:(c + 1) * per * unit]), per, B, depth) for c in range(3)]
+    assert d.launch_plan()["latency_layout"] > 0 and d.launch_plan()["packed_shared"] == 0
+    pairs = np.concatenate([o[0] for o in outs], axis=2); sub = np.concatenate([o[1] for o in outs], axis=1); peaks = np.concatenate([o[2] for o in outs], axis=1)
+    for s in range(S):
+        o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-7 * 256); assert o.load_bulk(blob) == 0
+        rp, rs, rk, _ = o.process(data[s][:per * 3 * unit], per * 3, B, depth)
+        assert np.array_equal(rp, pairs[s]), f"pairs differ, stream {s}: {np.argwhere(rp != pairs[s])[:3].tolist()}"
+        assert np.array_equal(rs, sub[s]), f"sub differs, stream {s}: {np.argwhere(rs != sub[s])[:3].tolist()}"
+        assert np.array_equal(rk, peaks[s]), f"peaks differ, stream {s}: {np.argwhere(rk != peaks[s])[:3].tolist()}"
+        assert o.status() == d.status(s), s
+    d.close()
+
+
 def test_enabled_only_leaves_silent_outputs_unwritten(monkeypatch):
     """DSPI_OUT_ENABLED_ONLY (include/dspi.h): silent outputs (disabled pairs, the sub while off) may stay unwritten — the latency
     layout skips their stores —, every live word, peak and status byte is what it is without the flag."""
@@ -151,7 +181,8 @@ def test_enabled_only_leaves_silent_outputs_unwritten(monkeypatch):
 def test_latency_layout_mixed_with_other_kernels(flavor, monkeypatch):
     """One context, three kernels in a call: most stream pairs share the latency-class preset (latency layout), a few streams get presets
     of their own (per-lane kernels), and one group gets the leveller switched on (packed kernel).  Then the shared preset changes class
-    (an output EQ band becomes active): the context moves to the packed kernel on the same state arrays, mid-stream; tiled words."""
+    twice, mid-stream, on the same state arrays: an output EQ band becomes active (the latency layout's second shape: output rows), then
+    the leveller is switched on (the packed kernel); tiled words."""
     monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
     fs, B, blocks, S = 48000, 48, 12, 300
     blob = _latency_blob(xfeed=True, loud=False)
@@ -159,25 +190,34 @@ def test_latency_layout_mixed_with_other_kernels(flavor, monkeypatch):
     def special(x, s):
         if s in (5, 130): x.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -8.0)) if isinstance(x, Oracle) else x.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -8.0), stream=s)
     for s in (5, 130): special(d, s)
-    pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
+    pcm = WL.synth_pcm16(S, B * blocks * 3, fs)
     o1 = d.process_host(np.ascontiguousarray(pcm[:, :B * blocks]), blocks, B, tiled=True)
     plan = d.launch_plan()
     assert plan["latency_layout"] > 0 and plan["packed_per_lane_values"] + plan["one_stream_per_lane_images"] > 0, plan      # rows 0-1: per-lane values, row 2: latency layout
     p1, s1 = d.untile(o1[0], o1[1])
-    # class change for everyone: output 1 gets a live EQ band -> packed kernel from here on
+    # class change for everyone: output 1 gets a live EQ band -> output rows from here on
     eq = struct.pack("<BBBBfff", 3, 2, W.FILTER_PEAKING, 0, 900.0, 1.2, 4.0)
     d.vendor_set(W.REQ["SET_EQ_PARAM"], 0, eq)
-    o2 = d.process_host(np.ascontiguousarray(pcm[:, B * blocks:]), blocks, B, tiled=True)
-    assert d.launch_plan()["latency_layout"] == 0
+    o2 = d.process_host(np.ascontiguousarray(pcm[:, B * blocks:2 * B * blocks]), blocks, B, tiled=True)
+    plan = d.launch_plan()
+    assert plan["latency_layout"] > 0 and plan["packed_shared"] == 0, plan
     p2, s2 = d.untile(o2[0], o2[1])
+    # ... and the leveller on: the packed kernel
+    d.vendor_set(W.REQ["SET_LEVELLER_ENABLE"], 0, b"\x01")
+    o3 = d.process_host(np.ascontiguousarray(pcm[:, 2 * B * blocks:]), blocks, B, tiled=True)
+    assert d.launch_plan()["latency_layout"] == 0
+    p3, s3 = d.untile(o3[0], o3[1])
     for s in (0, 4, 5, 6, 129, 130, 131, 255, 256, S - 1):
         o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-9 * 256); assert o.load_bulk(blob) == 0
         special(o, s)
         rp, rs, rk, _ = o.process(pcm[s][:B * blocks], blocks, B)
         assert np.array_equal(rp, p1[s]) and np.array_equal(rs, s1[s]) and np.array_equal(rk, o1[2][s]), ("first call", s)
         o.vendor_set(W.REQ["SET_EQ_PARAM"], 0, eq)
-        rp, rs, rk, _ = o.process(pcm[s][B * blocks:], blocks, B)
-        assert np.array_equal(rp, p2[s]) and np.array_equal(rs, s2[s]) and np.array_equal(rk, o2[2][s]), ("after the class change", s)
+        rp, rs, rk, _ = o.process(pcm[s][B * blocks:2 * B * blocks], blocks, B)
+        assert np.array_equal(rp, p2[s]) and np.array_equal(rs, s2[s]) and np.array_equal(rk, o2[2][s]), ("after the first class change", s)
+        o.vendor_set(W.REQ["SET_LEVELLER_ENABLE"], 0, b"\x01")
+        rp, rs, rk, _ = o.process(pcm[s][2 * B * blocks:], blocks, B)
+        assert np.array_equal(rp, p3[s]) and np.array_equal(rs, s3[s]) and np.array_equal(rk, o3[2][s]), ("after the second class change", s)
         assert o.status() == d.status(s)
     d.close()
 
