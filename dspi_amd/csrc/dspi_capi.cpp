@@ -272,9 +272,10 @@ dspi_ctx::ImageSig make_sig(const DevImage &img) {
 // The latency layout of the float chain (dspi_chain_skew.inc) serves images with the leveller off.  Class 1: no output runs an EQ
 // (disabled, muted, every band flat, or the sub in EQ-worker mode: exactly the cases in which output_item_pk skips the band loops) —
 // eight stream pairs per workgroup, the outputs frame-parallel.  Class 2: some output does — two pairs per workgroup, every output a
-// systolic row of its own.  0: not served (leveller on: its two passes per packet need the ring hand-off).
+// systolic row of its own.  Class 3: the leveller is on — the same two pairs and output rows, the groups of the workgroup passing frames
+// through rings (dspi_chain_skew_lev.inc).
 int skew_class(const dspi_ctx::ImageSig &g) {
-    if (g.flags & IF_LEVELLER_ON) return 0;
+    if (g.flags & IF_LEVELLER_ON) return 3;
     for (int o = 0; o < kMaxOut; o++) {
         const bool enabled = (g.out_enabled >> o) & 1u, muted = (g.out_mute >> o) & 1u, flat = (g.ch_bypassed >> (2 + o)) & 1u;
         const bool processed = o != kMaxOut - 1 || (g.flags & IF_SUB_ACTIVE);
@@ -289,7 +290,7 @@ uint32_t skew_pair_limit(int device, int cls) {
     if (const char *e = getenv("DSPI_F32_LAYOUT")) { if (!strcmp(e, "skew")) return 0xffffffffu; if (!strcmp(e, "packed")) return 0u; }
     int cus = 0;
     if (device < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-    return (cls == 2 ? 4u : 8u) * (uint32_t)cus;
+    return (cls == 1 ? 8u : 4u) * (uint32_t)cus;
 }
 
 dspi_ctx::BandHash hash_bands(const DevImage &img) {
@@ -395,16 +396,18 @@ int rebuild_launch_lists(dspi_ctx *c) {
     // float, shared-preset lanes with the leveller off: those whose image suits the latency layout move to list 5 / 6 (by class) when
     // the launch is small enough to leave the chip underfilled
     if (c->flavor && c->image_sig.size() >= c->images.size()) {
-        auto &v = c->launch_items[0][1];
-        uint64_t pairs[3] = {0, 0, 0};
-        for (const WgItem &it : v) pairs[skew_class(c->image_sig[it.image])] += (uint64_t)__builtin_popcountll(it.mask);
-        bool take[3] = {false, false, false};
-        for (int cls = 1; cls <= 2; cls++) take[cls] = pairs[cls] > 0 && pairs[cls] <= skew_pair_limit(c->device, cls);
-        if (take[1] || take[2]) {
+        uint64_t pairs[4] = {0, 0, 0, 0};
+        for (int lev = 0; lev < 2; lev++)
+            for (const WgItem &it : c->launch_items[lev][1]) pairs[skew_class(c->image_sig[it.image])] += (uint64_t)__builtin_popcountll(it.mask);
+        bool take[4] = {false, false, false, false};
+        for (int cls = 1; cls <= 3; cls++) take[cls] = pairs[cls] > 0 && pairs[cls] <= skew_pair_limit(c->device, cls);
+        for (int lev = 0; lev < 2; lev++) {
+            auto &v = c->launch_items[lev][1];
             std::vector<WgItem> keep;
             for (const WgItem &it : v) {
                 const int cls = skew_class(c->image_sig[it.image]);
-                (take[cls] ? c->launch_items[0][4 + cls] : keep).push_back(it);
+                // (class 3 sits in the leveller-on lists: list 5 there is the third shape)
+                (take[cls] ? c->launch_items[lev][cls == 2 ? 6 : 5] : keep).push_back(it);
             }
             v.swap(keep);
         }
@@ -751,7 +754,7 @@ int dspi_debug_launch_plan(dspi_ctx *c, uint32_t *counts, size_t n_counts) {
     if (!c || !counts || n_counts < 5) return DSPI_E_INVAL;
     const int n = n_counts >= 6 ? 6 : 5;      // [5]: items of the latency layout (dspi_chain_skew.inc)
     for (int k = 0; k < n; k++) counts[k] = (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size());
-    if (n == 6) counts[5] += (uint32_t)c->launch_items[0][6].size();      // both shapes of the latency layout
+    if (n == 6) counts[5] += (uint32_t)(c->launch_items[0][6].size() + c->launch_items[1][6].size());      // every shape of the latency layout
     if (c->flavor) counts[0] = 0;      // (list 0 of a float context is bookkeeping for the state mutations, never launched)
     return n;
 }

@@ -1145,6 +1145,7 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const S
 
 #include "dspi_chain_pk.inc"
 #include "dspi_chain_skew.inc"
+#include "dspi_chain_skew_lev.inc"
 
 // ==========================================================================================
 // the one-stream-per-lane kernel (Q28 flavour; float flavour: lanes whose two streams differ in image)
@@ -1620,7 +1621,7 @@ DSPI_PK_FAMILY(5, true, true, true)
 #endif
 
 // the latency layout of the float chain (dspi_chain_skew.inc): part 7
-hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, bool out_rows, hipStream_t stream);
+hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream);
 #if !defined(DSPI_PART) || DSPI_PART == 7
 template <bool EQO>
 static hipError_t launch_chain_skew_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
@@ -1642,8 +1643,28 @@ static hipError_t launch_chain_skew_t(const KArgs &args, uint32_t n_items, hipSt
     else { if (p24) hipLaunchKernelGGL((chain_kernel_skew<false, true, EQO>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<false, false, EQO>), grid, block, lds, stream, args); }
     return hipGetLastError();
 }
-hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, bool out_rows, hipStream_t stream) {
-    return out_rows ? launch_chain_skew_t<true>(args, n_items, stream) : launch_chain_skew_t<false>(args, n_items, stream);
+static hipError_t launch_chain_skew_lev(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    const dim3 grid(n_items * (64 / kSlPairs)), block(64 * kSlWaves);
+    const size_t lds = sizeof(SlShared);
+    static bool attr_set[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
+    if (!attr_set[dev] || dev == kMaxDevices - 1) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew_lev<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew_lev<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew_lev<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew_lev<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const bool p24 = args.bit_depth == 24;
+    if (args.fma) { if (p24) hipLaunchKernelGGL((chain_kernel_skew_lev<true, true>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew_lev<true, false>), grid, block, lds, stream, args); }
+    else { if (p24) hipLaunchKernelGGL((chain_kernel_skew_lev<false, true>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew_lev<false, false>), grid, block, lds, stream, args); }
+    return hipGetLastError();
+}
+hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream) {      // shape 1 / 2 / 3: dspi_capi.cpp skew_class
+    if (shape == 3) return launch_chain_skew_lev(args, n_items, stream);
+    return shape == 2 ? launch_chain_skew_t<true>(args, n_items, stream) : launch_chain_skew_t<false>(args, n_items, stream);
 }
 #endif
 
@@ -1706,7 +1727,7 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
     // per-lane images (float always; Q28 rows with several presets)
     if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
     // float: the context's contract (DSPI_FLOAT_CONTRACT_FMA) picks the kernel family
-    if (packed == 5 || packed == 6) return launch_chain_skew(args, n_items, packed == 6, stream);
+    if (packed == 5 || packed == 6) return launch_chain_skew(args, n_items, leveller_on ? 3 : (packed == 6 ? 2 : 1), stream);
     if (packed != 1 && packed != 3 && packed != 4) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
     if (packed == 3) return args.fma ? launch_chain_pk_f5(args, leveller_on, n_items, stream) : launch_chain_pk_f2(args, leveller_on, n_items, stream);
     if (packed == 4) return args.fma ? launch_chain_pk_f4(args, leveller_on, n_items, stream) : launch_chain_pk_f1(args, leveller_on, n_items, stream);

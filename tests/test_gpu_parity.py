@@ -151,6 +151,47 @@ def test_latency_layout_output_rows(flavor, fs, B, depth, monkeypatch):
     d.close()
 
 
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+@pytest.mark.parametrize("fs,B,depth,lookahead", [(48000, 48, 16, 1), (96000, 96, 24, 1), (44100, 45, 16, 0), (44100, 44, 24, 1), (48000, 1, 16, 1), (48000, 7, 16, 0), (48000, 13, 16, 1),
+                                                  (48000, 97, 16, 1), (96000, 192, 16, 1)])
+def test_latency_layout_leveller(flavor, fs, B, depth, lookahead, monkeypatch):
+    """The latency layout's third shape (dspi_chain_skew_lev.inc): BASELINE config 3's preset itself — leveller ON (its per-packet gain
+    decision, the ramp, the gain-cap limiter on look-ahead-delayed samples), crossfeed, nine equalised outputs — on a small context.
+    Four calls, so that the look-ahead line and the envelopes cross launch boundaries; then the same context continues on the packed
+    kernel (DSPI_F32_LAYOUT=packed) and must carry on where the latency layout left the rings and states, and back."""
+    blob = WL.full_chain_blob(1)
+    blob["leveller"]["lookahead"] = lookahead
+    blocks = 32 if B >= 44 else 200
+    S = 7
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-7 * 256); assert d.load_bulk(blob) == 0
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm)
+    per = blocks // 4
+    unit = B if depth == 16 else B * 6
+    outs = []
+    tweak = lambda c: struct.pack("<BBBBfff", 0, 3, W.FILTER_PEAKING, 0, 700.0, 1.1, 1.5 * c)
+    for c in range(4):
+        monkeypatch.setenv("DSPI_F32_LAYOUT", "packed" if c == 2 else "skew")
+        if c >= 2: d.vendor_set(W.REQ["SET_EQ_PARAM"], 0, tweak(c))      # (a band changes: the launch lists are rebuilt, under the new setting)
+        outs.append(d.process_host(np.ascontiguousarray(data[:, c * per * unit:(c + 1) * per * unit]), per, B, depth))
+        plan = d.launch_plan()
+        assert (plan["latency_layout"] == 0) == (c == 2) and (plan["packed_shared"] > 0) == (c == 2), (c, plan)
+    pairs = np.concatenate([o[0] for o in outs], axis=2); sub = np.concatenate([o[1] for o in outs], axis=1); peaks = np.concatenate([o[2] for o in outs], axis=1)
+    for s in range(S):
+        o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-7 * 256); assert o.load_bulk(blob) == 0
+        parts = []
+        for c in range(4):
+            if c >= 2: o.vendor_set(W.REQ["SET_EQ_PARAM"], 0, tweak(c))
+            parts.append(o.process(data[s][c * per * unit:(c + 1) * per * unit], per, B, depth))
+        rp = np.concatenate([q[0] for q in parts], axis=1); rs = np.concatenate([q[1] for q in parts]); rk = np.concatenate([q[2] for q in parts])
+        assert np.array_equal(rp, pairs[s]), f"pairs differ, stream {s}: {np.argwhere(rp != pairs[s])[:3].tolist()}"
+        assert np.array_equal(rs, sub[s]), f"sub differs, stream {s}: {np.argwhere(rs != sub[s])[:3].tolist()}"
+        assert np.array_equal(rk, peaks[s]), f"peaks differ, stream {s}: {np.argwhere(rk != peaks[s])[:3].tolist()}"
+        assert o.status() == d.status(s), s
+    d.close()
+
+
 def test_enabled_only_leaves_silent_outputs_unwritten(monkeypatch):
     """DSPI_OUT_ENABLED_ONLY (include/dspi.h): silent outputs (disabled pairs, the sub while off) may stay unwritten — the latency
     layout skips their stores —, every live word, peak and status byte is what it is without the flag."""
