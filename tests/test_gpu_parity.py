@@ -223,7 +223,7 @@ def test_latency_layout_mixed_with_other_kernels(flavor, monkeypatch):
     """One context, three kernels in a call: most stream pairs share the latency-class preset (latency layout), a few streams get presets
     of their own (per-lane kernels), and one group gets the leveller switched on (packed kernel).  Then the shared preset changes class
     twice, mid-stream, on the same state arrays: an output EQ band becomes active (the latency layout's second shape: output rows), then
-    the leveller is switched on (the packed kernel); tiled words."""
+    the leveller is switched on (its third shape); tiled words."""
     monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
     fs, B, blocks, S = 48000, 48, 12, 300
     blob = _latency_blob(xfeed=True, loud=False)
@@ -243,10 +243,11 @@ def test_latency_layout_mixed_with_other_kernels(flavor, monkeypatch):
     plan = d.launch_plan()
     assert plan["latency_layout"] > 0 and plan["packed_shared"] == 0, plan
     p2, s2 = d.untile(o2[0], o2[1])
-    # ... and the leveller on: the packed kernel
+    # ... and the leveller on: the third shape (rings between the groups)
     d.vendor_set(W.REQ["SET_LEVELLER_ENABLE"], 0, b"\x01")
     o3 = d.process_host(np.ascontiguousarray(pcm[:, 2 * B * blocks:]), blocks, B, tiled=True)
-    assert d.launch_plan()["latency_layout"] == 0
+    plan = d.launch_plan()
+    assert plan["latency_layout"] > 0 and plan["packed_shared"] == 0, plan
     p3, s3 = d.untile(o3[0], o3[1])
     for s in (0, 4, 5, 6, 129, 130, 131, 255, 256, S - 1):
         o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-9 * 256); assert o.load_bulk(blob) == 0

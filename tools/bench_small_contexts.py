@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Small contexts: the full float chain with the leveller off (BASELINE config 3's preset otherwise; the class of the latency layout's
-second shape, dspi_chain_skew.inc) at stream counts from 2 up, 96 kHz, 96-frame packets, 200 packets per launch, device buffers —
+"""Small contexts: BASELINE config 3's preset (LEVELLER=0: with the leveller off, the class of the latency layout's second shape; default:
+the third shape, dspi_chain_skew_lev.inc) at stream counts from 2 up, 96 kHz, 96-frame packets, 200 packets per launch, device buffers —
 the latency layout (the library's own choice, or DSPI_F32_LAYOUT=skew beyond its size rule) against the packed kernel
 (DSPI_F32_LAYOUT=packed).  One JSON line per (streams, layout)."""
 import json, os, subprocess, sys, time
@@ -13,7 +13,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     S = int(sys.argv[2]); B, blocks, fs = 96, 200, 96000
     FR = B * blocks
     dev = torch.device("cuda", 0)
-    blob = WL.full_chain_blob(1); blob["leveller"]["enabled"] = 0
+    blob = WL.full_chain_blob(1)
+    if os.environ.get("LEVELLER", "1") == "0": blob["leveller"]["enabled"] = 0
     d = Dspi(W.F32_FMA, S, device=0); d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(blob) == 0
     pcm = torch.randint(-16384, 16385, (S, FR, 2), dtype=torch.int16, device=dev)
     pairs = torch.empty((S, 4, FR, 2), dtype=torch.int32, device=dev); sub = torch.empty((S, FR), dtype=torch.int32, device=dev)
