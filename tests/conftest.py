@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "both_layouts: run the GPU test once on the packed float kernel and once on the latency layout (DSPI_F32_LAYOUT)")
+    config.addinivalue_line("markers", "auto_layout: leave the choice between the packed kernel and the latency layout to the library's size rule")
 
 
 @pytest.fixture(scope="session")
@@ -32,6 +34,24 @@ def q28_wave_layout(request, monkeypatch):
         if zlib.crc32(request.node.nodeid.encode()) & 1:
             monkeypatch.setenv("DSPI_Q28_WAVES", "4")
     yield
+
+
+@pytest.fixture(autouse=True)
+def _layout(request, monkeypatch):
+    """Float contexts of test size (a few hundred streams) would all take the latency layout (dspi_chain_skew*.inc: the library's choice
+    for launches that leave the chip underfilled) and the packed kernel — the one the headline is measured on — would only be seen by the
+    full-size tests.  So GPU tests pin the packed kernel (DSPI_F32_LAYOUT=packed) unless they say otherwise: `both_layouts` runs a test
+    once on each, `auto_layout` leaves the size rule in charge, and a test that sets the variable itself (monkeypatch) wins."""
+    if not request.node.get_closest_marker("gpu"):
+        yield; return
+    if request.node.get_closest_marker("auto_layout"): monkeypatch.delenv("DSPI_F32_LAYOUT", raising=False)
+    else: monkeypatch.setenv("DSPI_F32_LAYOUT", "skew" if getattr(request, "param", "packed") == "latency" else "packed")
+    yield
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("both_layouts") and "_layout" in metafunc.fixturenames:
+        metafunc.parametrize("_layout", ["packed", "latency"], indirect=True)
 
 
 def has_gpu() -> bool:

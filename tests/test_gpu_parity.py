@@ -54,6 +54,7 @@ def compare(flavor, fs, B, blocks, S, blob, vol=-20 * 256, depth=16, calls=2, ch
     d.close()
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_config2_master_peq(flavor):
     """BASELINE config 2 (float) / config 1 chain (Q28): master 10-band PEQ only; both SVF and biquad paths."""
@@ -65,6 +66,7 @@ def test_config2_master_peq(flavor):
         compare(0, 48000, 48, 20, 5, WL.config1_blob(), vol=0)
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 @pytest.mark.parametrize("fs,B,depth", [(96000, 96, 16), (48000, 48, 24), (44100, 45, 16), (44100, 44, 24)])
 def test_full_chain(flavor, fs, B, depth):
@@ -73,7 +75,12 @@ def test_full_chain(flavor, fs, B, depth):
     compare(flavor, fs, B, 24, 85, WL.full_chain_blob(flavor), depth=depth)
 
 
-def _latency_blob(xfeed=True, loud=True, delays=(0.0, 0.3, 1.7, 0.0, 95.0, 0.05, 12.0, 0.0, 3.0)):
+# delays of every class at 44.1 / 48 / 96 kHz: none, shorter than 64 frames, than a packet, a few packets, within a packet's length of the line's
+# 4096 positions (42.6 ms at 96 kHz, 85.2 ms at 48 kHz, 92.8 ms at 44.1 kHz: the rows just ahead of the write index), at and beyond them (alias)
+_EDGE_DELAYS = (0.0, 0.3, 42.6, 0.0, 95.0, 0.05, 85.2, 1.7, 92.8)
+
+
+def _latency_blob(xfeed=True, loud=True, delays=_EDGE_DELAYS):
     """A preset of the latency layout's class: master PEQ (+ loudness, crossfeed), leveller off, outputs routed, gained and delayed
     but without EQ; output 3 muted, output 5 disabled, crosspoint patterns both / left only / right only / inverted."""
     b = WL.config2_blob(False)
@@ -131,6 +138,7 @@ def test_latency_layout_output_rows(flavor, fs, B, depth, monkeypatch):
     monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
     blob = WL.full_chain_blob(1)
     blob["leveller"]["enabled"] = 0
+    for o in range(9): blob["outputs"][o]["delay_ms"] = _EDGE_DELAYS[o]
     blocks = 24 if B >= 44 else 150
     S = 11          # five pairs + a pair that holds one stream: three workgroups, the last one half filled
     d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-7 * 256); assert d.load_bulk(blob) == 0
@@ -161,6 +169,7 @@ def test_latency_layout_leveller(flavor, fs, B, depth, lookahead, monkeypatch):
     kernel (DSPI_F32_LAYOUT=packed) and must carry on where the latency layout left the rings and states, and back."""
     blob = WL.full_chain_blob(1)
     blob["leveller"]["lookahead"] = lookahead
+    for o in range(9): blob["outputs"][o]["delay_ms"] = _EDGE_DELAYS[(o + 3) % 9]
     blocks = 32 if B >= 44 else 200
     S = 7
     monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
@@ -275,6 +284,7 @@ def test_q28_wave_layouts(waves, monkeypatch):
     compare(0, 44100, 45, 20, 70, WL.full_chain_blob(0), depth=24, calls=2, first_stream=15)
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 @pytest.mark.parametrize("lev", [1, 0])
 def test_ragged_packets_delay_edges(flavor, lev):
@@ -294,6 +304,7 @@ def test_ragged_packets_delay_edges(flavor, lev):
     compare(flavor, 44100, 44, 30, 9, b, depth=24, calls=2, first_stream=14)
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 @pytest.mark.parametrize("B", [1, 7, 17, 97])
 def test_unusual_packet_lengths(flavor, B):
@@ -302,6 +313,7 @@ def test_unusual_packet_lengths(flavor, B):
     compare(flavor, 48000, B, 200 if B < 4 else 40, 9, WL.full_chain_blob(flavor), calls=2)
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_long_run_wraps_delay_lines(flavor):
     """More frames than a delay line holds (4096 float / 2048 Q28 positions): the shared write index wraps, the 80 ms /
@@ -310,12 +322,14 @@ def test_long_run_wraps_delay_lines(flavor):
     compare(flavor, fs, B, 54, 6, WL.full_chain_blob(flavor), calls=3, first_stream=2)
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_host_volume_sign_quirk_and_mute(flavor):
     compare(flavor, 96000 if flavor else 48000, 96 if flavor else 48, 12, 6, WL.full_chain_blob(flavor), vol=0)
     compare(flavor, 48000, 48, 12, 3, WL.full_chain_blob(flavor), setup=lambda x: x.set_mute(True))
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_vendor_requests_between_launches(flavor):
     """Parameter changes land on packet boundaries and carry their state side effects (filter path resets, crossfeed /
@@ -556,6 +570,7 @@ def test_every_stream_its_own_preset(flavor, fs, B, depth, S):
     d.close()
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_tiled_output_layout(flavor):
     """DSPI_OUT_TILED ([tile][output][frame][R]) carries exactly the words of the stream-major layout: packed and
@@ -579,6 +594,7 @@ def test_tiled_output_layout(flavor):
     for d in ctx: d.close()
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_fixtures_on_gpu(path):
     """Vectors generated from the reference's own leaf sources (tests/golden/make_golden.py).  Skipped: the glibc-libm vector
@@ -697,6 +713,7 @@ def test_full_size_stream_major_groups_agree(flavor, fs, B, blocks):
     d.close()
 
 
+@pytest.mark.auto_layout
 @pytest.mark.parametrize("two_b", (False, True), ids=("config2", "config2b"))
 def test_full_size_config2_latency_layout(two_b):
     """BASELINE config 2 at the size bench.py --config 2 times it: 4 096 streams (one workgroup of eight stream pairs on every CU), 48-frame
@@ -782,7 +799,7 @@ def test_i2s_slot_words_fused_into_the_chain(flavor, tiled, monkeypatch):
     n_pairs = 4 if flavor else 2
     def setup(d, latency_class):
         d.set_rate(fs); d.set_volume(-5 * 256)
-        assert d.load_bulk(_latency_blob() if latency_class else WL.full_chain_blob(int(flavor))) == 0
+        assert d.load_bulk(_latency_blob(delays=(0.0, 0.3, 1.7, 0.0, 95.0, 0.05, 12.0, 0.0, 3.0)) if latency_class else WL.full_chain_blob(int(flavor))) == 0      # (delays within the 40 packets)
         d.vendor_get(W.REQ["SET_OUTPUT_TYPE"], 1 | (1 << 8), cap=1, stream=-1)                    # slot 1 -> I2S, every stream (DSPI_ALL_STREAMS)
         for s in (3, 70): d.vendor_get(W.REQ["SET_OUTPUT_TYPE"], 0 | (1 << 8), cap=1, stream=s)   # slot 0 too, two streams only
         if flavor and not latency_class: d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -7.5), stream=270)
@@ -799,13 +816,15 @@ def test_i2s_slot_words_fused_into_the_chain(flavor, tiled, monkeypatch):
             mask = 0b10 | (0b01 if s in (3, 70) else 0)
             for pr in range(n_pairs):
                 if mask & (1 << pr): want[s, pr] = (want[s, pr].astype(np.uint32) << np.uint32(8)).astype(np.int32)
-        assert np.array_equal(p1, want) and np.array_equal(s1, s0) and np.array_equal(k1, k0), latency_class
+        assert np.array_equal(p1, want), (latency_class, np.argwhere(p1 != want)[:4].tolist())
+        assert np.array_equal(s1, s0) and np.array_equal(k1, k0), latency_class
         assert int(np.abs(p0[0, 1, -B:]).max()) > 0 and int(np.abs(p0[3, 0, -B:]).max()) > 0
         if latency_class: assert fused.launch_plan()["latency_layout"] > 0
         elif flavor: assert fused.launch_plan()["packed_per_lane_values"] > 0
         plain.close(); fused.close()
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
 def test_boot_from_populated_flash_has_no_first_boot_mute(flavor):
     """DSPI_BOOT_POPULATED_FLASH: a context of devices that do NOT boot for the first time starts unmuted — the default context arms the
@@ -832,6 +851,7 @@ def test_boot_from_populated_flash_has_no_first_boot_mute(flavor):
     d.close(); muted.close()
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_flash_dump_boots_device_context(flavor):
     """SURVEY 8f-4 on the GPU: dspi_load_flash_dump on a DEVICE context (v2 directory, v1 directory, corrupt selected slot -> factory
