@@ -36,8 +36,9 @@ size_t chain_lds_bytes(int flavor, int packed);
 // packed 3 = packed float kernel with per-lane VALUES: one item per row whose streams share a structure, WgItem::image = any
 // image of the row (read for the structure only), numbers from args.vals; packed 4 = the same for rows whose presets have identical
 // FILTERS (band coefficients from the image's scalars, everything else from args.vals)
-// packed 5 = the latency layout of the float chain (dspi_chain_skew.inc): items as for packed 1, images with the leveller off and no
-// active output EQ, launches small enough to leave the chip underfilled (dspi_capi.cpp decides)
+// packed 5 / 6 = the latency layout of the float chain (dspi_chain_skew.inc, dspi_chain_skew_lev.inc): items as for packed 1, launches small
+// enough to leave the chip underfilled (dspi_capi.cpp decides).  5 with leveller_on false: images without an active output EQ; 6: with
+// one; 5 with leveller_on true: images with the leveller on (the third shape)
 // leveller_on: IF_LEVELLER_ON of every image in args.items (the host groups them; the packed kernel is specialised on it)
 hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &args, uint32_t n_items, hipStream_t stream);
 hipError_t launch_state_ops(int flavor, const WgItem *items, uint32_t n_items, const StateOps &ops, uint32_t *state, uint32_t *dlines,
