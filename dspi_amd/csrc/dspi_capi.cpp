@@ -51,6 +51,7 @@ struct dspi_ctx {
     WgItem *d_litems = nullptr; size_t d_litems_cap = 0;
     uint32_t *d_stream_image = nullptr; size_t d_stream_image_cap = 0;   // image index per stream (per-lane parameter kernel)
     bool launch_dirty = true;
+    uint32_t spdif_pos = 0;      // DSPI_OUT_SPDIF: block position of the next call's first frame
     // device
     hipStream_t hs = nullptr;
     // host-buffer dspi_process: H2D, kernels and D2H of consecutive row chunks overlap on three streams (created on first use)
@@ -399,6 +400,13 @@ int rebuild_launch_lists(dspi_ctx *c) {
         uint64_t pairs[4] = {0, 0, 0, 0};
         for (int lev = 0; lev < 2; lev++)
             for (const WgItem &it : c->launch_items[lev][1]) pairs[skew_class(c->image_sig[it.image])] += (uint64_t)__builtin_popcountll(it.mask);
+        // the context's last stream when the stream count is odd: a lane that holds one stream.  The packed kernel leaves such lanes to the
+        // one-stream kernel (list 2); the latency layout serves them (its stores check the second stream) — a context of ONE stream is this case
+        const bool odd = (c->n_streams & 1u) != 0;
+        const uint32_t last = c->n_streams - 1u, h_row = last / (uint32_t)c->sm.row, h_lane = (last % (uint32_t)c->sm.row) / 2u;
+        const uint32_t h_img = odd ? c->stream_image[last] : 0u;
+        const int h_cls = (odd && !c->row_pv[h_row]) ? skew_class(c->image_sig[h_img]) : 0;
+        if (h_cls) pairs[h_cls]++;
         bool take[4] = {false, false, false, false};
         for (int cls = 1; cls <= 3; cls++) take[cls] = pairs[cls] > 0 && pairs[cls] <= skew_pair_limit(c->device, cls);
         for (int lev = 0; lev < 2; lev++) {
@@ -410,6 +418,22 @@ int rebuild_launch_lists(dspi_ctx *c) {
                 (take[cls] ? c->launch_items[lev][cls == 2 ? 6 : 5] : keep).push_back(it);
             }
             v.swap(keep);
+        }
+        if (h_cls && take[h_cls]) {
+            auto &l2 = c->launch_items[0][2];
+            for (size_t i = 0; i < l2.size(); i++)
+                if (l2[i].wg == h_row && l2[i].image == 0u && ((l2[i].mask >> h_lane) & 1ull)) {      // (list 2: image = lane component, 0 = first stream)
+                    l2[i].mask &= ~(1ull << h_lane);
+                    if (l2[i].mask == 0) l2.erase(l2.begin() + (long)i);
+                    auto &dst = c->launch_items[h_cls == 3 ? 1 : 0][h_cls == 2 ? 6 : 5];
+                    bool merged = false;
+                    for (WgItem &d : dst) if (d.wg == h_row && d.image == h_img) { d.mask |= 1ull << h_lane; merged = true; break; }
+                    if (!merged) {
+                        dst.push_back(WgItem{h_row, h_img, 1ull << h_lane, 0ull});
+                        std::stable_sort(dst.begin(), dst.end(), [](const WgItem &x, const WgItem &y) { return x.wg < y.wg; });
+                    }
+                    break;
+                }
         }
     }
     for (int lev = 0; lev < 2; lev++)
@@ -884,6 +908,12 @@ int dspi_i2s_encode(dspi_ctx *c, const int32_t *pairs, uint32_t n_frames, uint32
     return (int)pair_mask;
 }
 
+int dspi_spdif_block_pos(dspi_ctx *c, int32_t set) {
+    if (!c || set >= 192) return DSPI_E_INVAL;
+    if (set >= 0) c->spdif_pos = (uint32_t)set;
+    return (int)c->spdif_pos;
+}
+
 int dspi_sync(dspi_ctx *c) {
     if (!c) return DSPI_E_INVAL;
     if (c->device == DSPI_DEVICE_NONE) return DSPI_E_NODEVICE;
@@ -903,8 +933,18 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     const size_t frames = (size_t)n_blocks * block_len;
     const size_t in_b = (size_t)c->n_streams * frames * (bit_depth == 24 ? 6 : 4);
     const bool tiled = flags & DSPI_OUT_TILED;
+    const bool spdif = flags & DSPI_OUT_SPDIF;
+    if (spdif) {
+        if (tiled || (flags & DSPI_OUT_I2S_SLOTS)) return fail(c, DSPI_E_INVAL, "DSPI_OUT_SPDIF goes with neither DSPI_OUT_TILED nor DSPI_OUT_I2S_SLOTS");
+        // only the latency layout's output waves encode subframes: every lane of the launch must be on it
+        bool all_latency = c->flavor != 0;
+        for (int lev = 0; lev < 2 && all_latency; lev++)
+            for (int k = 1; k <= 4; k++) if (!c->launch_items[lev][k].empty()) all_latency = false;
+        if (!all_latency)
+            return fail(c, DSPI_E_UNSUPPORTED, "DSPI_OUT_SPDIF is served by the float chain's latency layout (shared presets, up to 2 048 streams): use dspi_spdif_encode after dspi_process here");
+    }
     const size_t padded = (size_t)c->n_wg * c->sm.row;          // tiled buffers cover whole tiles
-    const size_t pairs_b = tiled ? padded * (c->sm.n_out - 1) * frames * 4 : (size_t)c->n_streams * c->sm.n_pairs * frames * 8;
+    const size_t pairs_b = tiled ? padded * (c->sm.n_out - 1) * frames * 4 : (size_t)c->n_streams * c->sm.n_pairs * frames * (spdif ? 16 : 8);
     const size_t sub_b = (tiled ? padded : (size_t)c->n_streams) * frames * 4;
     const size_t peaks_b = (size_t)c->n_streams * n_blocks * c->sm.n_ch * 2;
     const bool dev = flags & DSPI_MEM_DEVICE;
@@ -916,6 +956,11 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.fma = c->fma ? 1u : 0u;
     a.skip_silent = (flags & DSPI_OUT_ENABLED_ONLY) ? 1u : 0u;
     a.i2s_slots = (flags & DSPI_OUT_I2S_SLOTS) ? 1u : 0u;
+    if (spdif) {
+        a.spdif = 1u; a.spdif_pos = c->spdif_pos;
+        spdif_status_words(readable(c, DSPI_ALL_STREAMS).freq, a.spdif_lo, a.spdif_hi);
+        c->spdif_pos = (uint32_t)((c->spdif_pos + frames) % 192u);
+    }
     if (c->flavor && !tiled && (out->pairs || out->sub)) {      // stream-major words of the packed kernel go through its exchange area
         const size_t xb = (size_t)c->n_wg * 2 * kMaxOut * kChunk * c->sm.row * 4;
         if ((rc = ensure(c, c->d_xwords, c->d_xwords_cap, xb))) return rc;
@@ -1013,7 +1058,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         // tiled words: whole tiles [tile][...]; stream-major: [stream][...] — either way a row range is one contiguous piece
         const size_t t0 = tiled ? (size_t)r0 * row : s0, t1 = tiled ? (size_t)r1 * row : s1;
         if (out->pairs) {
-            const size_t per = tiled ? (size_t)(c->sm.n_out - 1) * frames * 4 : (size_t)c->sm.n_pairs * frames * 8;
+            const size_t per = tiled ? (size_t)(c->sm.n_out - 1) * frames * 4 : (size_t)c->sm.n_pairs * frames * (spdif ? 16 : 8);
             if ((he = hipMemcpyAsync(reinterpret_cast<char *>(out->pairs) + t0 * per, reinterpret_cast<char *>(c->d_pairs) + t0 * per, (t1 - t0) * per, hipMemcpyDeviceToHost, sout)) != hipSuccess) return fail_hip(he, "D2H pairs");
         }
         if (out->sub) {

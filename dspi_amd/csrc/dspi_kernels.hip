@@ -27,6 +27,7 @@
 #include "../../include/dspi_detmath.h"
 #include "dspi_image.h"
 #include "dspi_kernels.h"
+#include "dspi_spdif_dev.h"
 
 namespace dspi {
 

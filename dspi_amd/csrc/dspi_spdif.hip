@@ -16,29 +16,11 @@
 #include <stdint.h>
 
 #include "dspi_kernels.h"
+#include "dspi_spdif_dev.h"
 
 namespace dspi {
 
 namespace {
-
-// spdif_lookup[b] (audio_spdif.c:141-153): low 16 bits = 0x5555 | (bit j of b) << (2j+1), bit 16 = parity of b
-__device__ __forceinline__ uint32_t bmc_byte(uint32_t b) {
-    uint32_t x = b & 0xffu;
-    x = (x | (x << 4)) & 0x0f0fu;
-    x = (x | (x << 2)) & 0x3333u;
-    x = (x | (x << 1)) & 0x5555u;
-    return 0x5555u | (x << 1) | ((uint32_t)(__builtin_popcount(b & 0xffu) & 1) << 16);
-}
-
-// spdif_update_subframe on a pre-filled subframe {preamble, 0x55000000 | c << 29} (sample_encoding.h:27-47)
-__device__ __forceinline__ void subframe(uint32_t sample, uint32_t preamble, uint32_t c_bit, uint32_t &l, uint32_t &h) {
-    const uint32_t s0 = bmc_byte(sample), s1 = bmc_byte(sample >> 8), s2 = bmc_byte(sample >> 16);
-    l = preamble | ((s0 & 0xffffu) << 8) | (s1 << 24);
-    const uint32_t ph = 0x55u | (c_bit << 5);
-    uint32_t p = (s0 >> 16) ^ (s1 >> 16) ^ (s2 >> 16);
-    p ^= (((ph & 0x2au) * 0x2au) >> 6) & 1u;
-    h = ((s1 & 0xffffu) >> 8) | ((s2 & 0xffffu) << 8) | ((ph & 0x7fu) << 24) | (p << 31);
-}
 
 constexpr uint32_t kFrameSlice = 32;
 
@@ -164,8 +146,8 @@ hipError_t launch_i2s(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t 
 hipError_t launch_spdif(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
                         uint32_t n_wg, uint32_t block_pos, uint32_t fs, hipStream_t stream) {
     // IEC 60958-3 consumer channel status, 5 bytes (audio_spdif.c:83-89, sample-rate byte :250-256)
-    const uint32_t rate = fs == 44100 ? 0x00u : fs == 48000 ? 0x02u : fs == 96000 ? 0x0Au : 0x01u;
-    const uint32_t lo = 0x04u | (rate << 24), hi = 0x0Bu;
+    uint32_t lo, hi;
+    spdif_status_words(fs, lo, hi);
     if (tiled) hipLaunchKernelGGL(spdif_kernel<true>, dim3(n_wg, n_pairs, (n_frames + kFrameSlice - 1) / kFrameSlice), dim3(128), 0, stream, pairs, out, n_streams, n_pairs, n_frames, row, block_pos, lo, hi);
     else {
         const uint64_t total = (uint64_t)n_streams * n_pairs * n_frames;

@@ -19,6 +19,7 @@ MEM_DEVICE = 0x1
 OUT_TILED = 0x2
 OUT_ENABLED_ONLY = 0x4
 OUT_I2S_SLOTS = 0x8
+OUT_SPDIF = 0x10
 E_NODEVICE = -11
 E_UNSUPPORTED = -14
 
@@ -186,6 +187,10 @@ class Dspi:
         n = self._ck(self.L.dspi_debug_image(self.h, stream, buf, 8192), "debug_image")
         return buf.raw[:n]
 
+    def spdif_block_pos(self, set: int = -1) -> int:
+        """dspi_spdif_block_pos: position in the 192-frame channel-status block of the next DSPI_OUT_SPDIF call's first frame."""
+        return self._ck(self.L.dspi_spdif_block_pos(self.h, set), "spdif_block_pos")
+
     def launch_plan(self) -> dict:
         """dspi_debug_launch_plan: work items per kernel path after the last process call."""
         c = (C.c_uint32 * 6)()
@@ -210,10 +215,11 @@ class Dspi:
         return int(self.L.dspi_tile_streams(self.h))
 
     def process_host(self, pcm: np.ndarray, n_blocks: int, block_len: int, bit_depth: int = 16,
-                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False, out=None, enabled_only=False, i2s_slots=False):
+                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False, out=None, enabled_only=False, i2s_slots=False, spdif=False):
         """Host-memory convenience path (tests): pcm = int16 [streams][frames][2] or uint8 [streams][frames*6].
         Returns (pairs [S][P][F][2], sub [S][F], peaks [S][blocks][C]); with tiled=True the sample words come back in
-        the DSPI_OUT_TILED layout: pairs [tiles][outputs][F][R], sub [tiles][F][R] (see untile())."""
+        the DSPI_OUT_TILED layout: pairs [tiles][outputs][F][R], sub [tiles][F][R] (see untile()); with spdif=True (DSPI_OUT_SPDIF)
+        pairs are the IEC 60958 subframes, uint32 [S][P][F][4]."""
         S, F = self.n_streams, n_blocks * block_len
         pcm = np.ascontiguousarray(pcm)
         assert pcm.nbytes == S * F * (6 if bit_depth == 24 else 4), (pcm.shape, S, F)
@@ -225,11 +231,11 @@ class Dspi:
             pairs = np.zeros((nt, self.P * 2, F, R), dtype=np.int32) if want_pairs else None
             sub = np.zeros((nt, F, R), dtype=np.int32) if want_sub else None
         else:
-            pairs = np.zeros((S, self.P, F, 2), dtype=np.int32) if want_pairs else None
+            pairs = (np.zeros((S, self.P, F, 4), dtype=np.uint32) if spdif else np.zeros((S, self.P, F, 2), dtype=np.int32)) if want_pairs else None
             sub = np.zeros((S, F), dtype=np.int32) if want_sub else None
         peaks = np.zeros((S, n_blocks, self.C), dtype=np.uint16) if want_peaks else None
         out = _Out(pairs.ctypes.data if want_pairs else None, sub.ctypes.data if want_sub else None, peaks.ctypes.data if want_peaks else None)
-        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0)), "process")
+        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0) | (OUT_SPDIF if spdif else 0)), "process")
         return pairs, sub, peaks
 
     def untile(self, pairs_t: np.ndarray, sub_t: np.ndarray):
@@ -245,10 +251,10 @@ class Dspi:
         return pairs, sub
 
     def process_device(self, pcm_ptr: int, n_blocks: int, block_len: int, bit_depth: int = 16,
-                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0, tiled: bool = False, enabled_only: bool = False, i2s_slots: bool = False):
+                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0, tiled: bool = False, enabled_only: bool = False, i2s_slots: bool = False, spdif: bool = False):
         """Zero-copy path: raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous, see sync()."""
         out = _Out(pairs_ptr or None, sub_ptr or None, peaks_ptr or None)
-        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE | (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0)), "process")
+        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE | (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0) | (OUT_SPDIF if spdif else 0)), "process")
 
     def pdm_host(self, sub: np.ndarray, tiled: bool = False) -> np.ndarray:
         """PDM sub output (dspi_pdm_modulate) on host arrays: sub int32 [streams][frames] -> uint32 [streams][frames][8];

@@ -41,10 +41,10 @@
 extern "C" {
 #endif
 
-#define DSPI_ABI_VERSION 5   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
+#define DSPI_ABI_VERSION 6   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
                               * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1,
-                              * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, DSPI_OUT_I2S_SLOTS, DSPI_BOOT_POPULATED_FLASH, dspi_debug_launch_plan counts[5]
-                              * (additions only) */
+                              * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, DSPI_OUT_I2S_SLOTS, DSPI_BOOT_POPULATED_FLASH, dspi_debug_launch_plan counts[5];
+                              * 6: DSPI_OUT_SPDIF, dspi_spdif_block_pos (additions only) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -88,6 +88,15 @@ extern "C" {
                                     * the words the I2S driver shifts out — the S/PDIF producer word left-justified, word << 8
                                     * (pico_audio_i2s_multi/audio_i2s_multi.c:217-226) — instead of going through dspi_i2s_encode afterwards: the same
                                     * words, without the second pass over 64 bytes per frame.  S/PDIF-typed pairs are unaffected. */
+#define DSPI_OUT_SPDIF 0x10u       /* `pairs` takes what the S/PDIF driver shifts out instead of the producer words: per frame and pair the two IEC 60958
+                                    * subframes of spdif_update_subframe (pico_audio_spdif_multi, sample_encoding.h:27-47; dspi_spdif_encode below) —
+                                    *   pairs  uint32 [stream][pair][F][4]   {left lo, left hi, right lo, right hi}: TWICE the bytes of the word layout —
+                                    * the words dspi_process + dspi_spdif_encode give, without the second pass (8 bytes in, 16 out per frame and pair).
+                                    * The position in the 192-frame channel-status block runs on from call to call (dspi_spdif_block_pos).  Served by
+                                    * the float chain's latency layout (contexts of up to 2 048 streams, shared presets: its output waves hold both
+                                    * sides of a pair of a frame in one lane and have time to spare); launches that run on other kernels return
+                                    * DSPI_E_UNSUPPORTED — there the encoder would cost the chain 60 % more instructions and the
+                                    * two-call sequence is the fast path.  Not with DSPI_OUT_TILED or DSPI_OUT_I2S_SLOTS. */
 #define DSPI_OUT_ENABLED_ONLY 0x4u /* the caller does not read the sample words of SILENT outputs — an S/PDIF pair whose two outputs are
                                     * disabled (the firmware zero-fills it, usb_audio.c:930-933), the sub while it is disabled or Core 1
                                     * runs the EQ worker — so the library may leave those parts of pairs / sub unwritten instead of storing
@@ -205,6 +214,9 @@ int dspi_pdm_restart(dspi_ctx *ctx, int32_t stream);
  * block_pos = position of the first frame in the 192-frame channel-status block (0..191).  Returns the position that
  * follows the last frame (>= 0; feed it to the next call) or a negative DSPI_E_*. */
 int dspi_spdif_encode(dspi_ctx *ctx, const int32_t *pairs, uint32_t n_frames, uint32_t block_pos, uint32_t *subframes, uint32_t flags);
+/* DSPI_OUT_SPDIF: the position in the 192-frame block of the next dspi_process call's first frame (0 after dspi_create, then advanced by
+ * every call made with the flag).  set in 0..191 sets it first; set < 0 only reads.  Returns the position or a negative DSPI_E_*. */
+int dspi_spdif_block_pos(dspi_ctx *ctx, int32_t set);
 /* ---- I2S slots ----------------------------------------------------------- */
 /* An output slot switched to I2S (REQ_SET_OUTPUT_TYPE 0xC0 / output_types[] of a preset, config.h:286-287) takes the same
  * words as an S/PDIF slot and left-justifies them into 32-bit I2S slots, L then R, MSB first on the wire

@@ -201,6 +201,29 @@ def test_latency_layout_leveller(flavor, fs, B, depth, lookahead, monkeypatch):
     d.close()
 
 
+@pytest.mark.auto_layout
+@pytest.mark.parametrize("shape", (1, 2, 3))
+@pytest.mark.parametrize("S", (1, 3))
+def test_one_stream_context_takes_the_latency_layout(shape, S):
+    """The firmware's own use case: ONE stream (and three: a pair and a half).  A lane that holds a single stream is left to the one-stream
+    kernel by the packed kernel; the latency layout serves it, so such contexts run on it entirely — by the library's own choice."""
+    fs, B, blocks = 48000, 48, 30
+    blob = _latency_blob() if shape == 1 else WL.full_chain_blob(1)
+    if shape == 2: blob["leveller"]["enabled"] = 0
+    d = Dspi(W.F32_FMA, S, device=0); d.set_rate(fs); d.set_volume(-7 * 256); assert d.load_bulk(blob) == 0
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    outs = [d.process_host(np.ascontiguousarray(pcm[:, c * B * 10:(c + 1) * B * 10]), 10, B) for c in range(3)]
+    plan = d.launch_plan()
+    assert plan["latency_layout"] > 0 and plan["one_stream_per_lane_images"] == 0 and plan["packed_shared"] == 0, plan
+    pairs = np.concatenate([o[0] for o in outs], axis=2); sub = np.concatenate([o[1] for o in outs], axis=1); peaks = np.concatenate([o[2] for o in outs], axis=1)
+    for s in range(S):
+        o = Oracle(W.F32_FMA, detmath=True); o.set_rate(fs); o.set_volume(-7 * 256); assert o.load_bulk(blob) == 0
+        rp, rs, rk, _ = o.process(pcm[s], blocks, B)
+        assert np.array_equal(rp, pairs[s]) and np.array_equal(rs, sub[s]) and np.array_equal(rk, peaks[s]), s
+        assert o.status() == d.status(s), s
+    d.close()
+
+
 def test_enabled_only_leaves_silent_outputs_unwritten(monkeypatch):
     """DSPI_OUT_ENABLED_ONLY (include/dspi.h): silent outputs (disabled pairs, the sub while off) may stay unwritten — the latency
     layout skips their stores —, every live word, peak and status byte is what it is without the flag."""
@@ -822,6 +845,38 @@ def test_i2s_slot_words_fused_into_the_chain(flavor, tiled, monkeypatch):
         if latency_class: assert fused.launch_plan()["latency_layout"] > 0
         elif flavor: assert fused.launch_plan()["packed_per_lane_values"] > 0
         plain.close(); fused.close()
+
+
+@pytest.mark.parametrize("shape,fs,B", [(1, 48000, 48), (2, 96000, 96), (3, 44100, 45), (3, 48000, 7)])
+def test_spdif_subframes_fused_into_the_chain(shape, fs, B, monkeypatch):
+    """DSPI_OUT_SPDIF: the latency layout's output waves write the IEC 60958 subframes themselves — every shape of the layout, three calls
+    so that the block position runs across call boundaries (and a set position) — the words dspi_process + dspi_spdif_encode give, which
+    test_spdif_subframes pins to the reference's spdif_update_subframe.  A launch that is not on the latency layout refuses the flag."""
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    blob = _latency_blob() if shape == 1 else WL.full_chain_blob(1)
+    if shape == 2: blob["leveller"]["enabled"] = 0
+    blocks, S = (16 if B >= 44 else 120), 9
+    plain, fused = Dspi(W.F32_FMA, S, device=0), Dspi(W.F32_FMA, S, device=0)
+    for d in (plain, fused): d.set_rate(fs); d.set_volume(-6 * 256); assert d.load_bulk(blob) == 0
+    assert fused.spdif_block_pos(77) == 77
+    pos = 77
+    pcm = WL.synth_pcm16(S, B * blocks * 3, fs)
+    for c in range(3):
+        part = np.ascontiguousarray(pcm[:, c * B * blocks:(c + 1) * B * blocks])
+        p0, s0, k0 = plain.process_host(part, blocks, B)
+        want, nxt = plain.spdif_host(p0, pos)
+        p1, s1, k1 = fused.process_host(part, blocks, B, spdif=True)
+        assert fused.launch_plan()["latency_layout"] > 0
+        assert np.array_equal(p1, want), (c, np.argwhere(p1 != want)[:4].tolist())
+        assert np.array_equal(s1, s0) and np.array_equal(k1, k0), c
+        pos = nxt
+        assert fused.spdif_block_pos() == pos
+    assert int(np.abs(p0[0, 0, -B:]).max()) > 0
+    plain.close(); fused.close()
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "packed")
+    d = Dspi(W.F32_FMA, S, device=0); d.set_rate(fs); assert d.load_bulk(blob) == 0
+    with pytest.raises(Exception): d.process_host(np.ascontiguousarray(pcm[:, :B * blocks]), blocks, B, spdif=True)
+    d.close()
 
 
 @pytest.mark.both_layouts

@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps({"streams": S, "layout": "latency" if plan["latency_layout"] else "packed", "forced": os.environ.get("DSPI_F32_LAYOUT", ""), "ms_per_launch": dt * 1e3,
                       "frames_per_s": S * FR / dt, "realtime_x_per_stream": FR / fs / dt}))
     sys.exit(0)
-for S in (2, 16, 128, 512, 1024, 2048, 4096, 8192):
+for S in (1, 2, 16, 128, 512, 1024, 2048, 4096, 8192):
     for lay in ("", "skew", "packed"):
         env = dict(os.environ)
         if lay: env["DSPI_F32_LAYOUT"] = lay
