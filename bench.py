@@ -418,8 +418,11 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         kname = "chain_kernel_pk<false, true, false, %s, %s, %s, %s>" % ("true" if args.out_layout == "tiled" else "false", "true" if args.contract == "fma" else "false",
                                                                          "true" if w.get("perstream") else "false", "true" if w.get("perstream") == "eq" else "false")
         if CH == 2: kname = kname.replace("<false, true", "<false, false")
-        if primary.get("latency_layout"):      # small launches of presets without leveller / output EQ: the skewed cascade (dspi_chain_skew.inc)
-            kname = "chain_kernel_skew<%s, false>" % ("true" if args.contract == "fma" else "false")
+        if primary.get("latency_layout"):      # small launches: the skewed cascade (dspi_chain_skew.inc: no output EQ / output rows; dspi_chain_skew_lev.inc: leveller on)
+            fma_s = "true" if args.contract == "fma" else "false"
+            lev_on = bool(w["blob"]["leveller"]["enabled"])
+            out_eq = CH != 2
+            kname = ("chain_kernel_skew_lev<%s, false>" % fma_s) if lev_on else ("chain_kernel_skew<%s, false, %s>" % (fma_s, "true" if out_eq else "false"))
     else:
         # wave layout by launch size (dspi_kernels.hip chain_kernel NW): seven waves up to one 64-stream workgroup per CU, four beyond
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
