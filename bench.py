@@ -422,7 +422,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
             fma_s = "true" if args.contract == "fma" else "false"
             lev_on = bool(w["blob"]["leveller"]["enabled"])
             out_eq = CH != 2
-            kname = ("chain_kernel_skew_lev<%s, false>" % fma_s) if lev_on else ("chain_kernel_skew<%s, false, %s>" % (fma_s, "true" if out_eq else "false"))
+            kname = ("chain_kernel_skew_lev<%s, false, false>" % fma_s) if lev_on else ("chain_kernel_skew<%s, false, %s, false>" % (fma_s, "true" if out_eq else "false"))
     else:
         # wave layout by launch size (dspi_kernels.hip chain_kernel NW): seven waves up to one 64-stream workgroup per CU, four beyond
         cus = torch.cuda.get_device_properties(dev).multi_processor_count

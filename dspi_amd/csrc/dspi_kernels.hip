@@ -1624,44 +1624,35 @@ DSPI_PK_FAMILY(5, true, true, true)
 // the latency layout of the float chain (dspi_chain_skew.inc): part 7
 hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream);
 #if !defined(DSPI_PART) || DSPI_PART == 7
-template <bool EQO>
-static hipError_t launch_chain_skew_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
-    const dim3 grid(n_items * (64 / SkCfg<EQO>::pairs)), block(64 * kSkWaves);
-    const size_t lds = sizeof(SkShared<EQO>);
-    static bool attr_set[kMaxDevices] = {};      // per device, see launch_chain_t
+// one launcher for the instances of a shape: float contract x input word size, with or without the S/PDIF encoder in the output waves
+template <class F>
+static hipError_t sk_launch(const KArgs &args, dim3 grid, dim3 block, size_t lds, hipStream_t stream, bool (&attr_set)[kMaxDevices], F kernels) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
-    if (!attr_set[dev] || dev == kMaxDevices - 1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<true, true, EQO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<true, false, EQO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<false, true, EQO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew<false, false, EQO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+    if (!attr_set[dev] || dev == kMaxDevices - 1) {      // per device, see launch_chain_t
+        for (int i = 0; i < 8; i++) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernels[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         attr_set[dev] = true;
     }
-    const bool p24 = args.bit_depth == 24;
-    if (args.fma) { if (p24) hipLaunchKernelGGL((chain_kernel_skew<true, true, EQO>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<true, false, EQO>), grid, block, lds, stream, args); }
-    else { if (p24) hipLaunchKernelGGL((chain_kernel_skew<false, true, EQO>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew<false, false, EQO>), grid, block, lds, stream, args); }
+    const int idx = (args.fma ? 4 : 0) | (args.bit_depth == 24 ? 2 : 0) | (args.spdif ? 1 : 0);
+    hipLaunchKernelGGL(kernels[idx], grid, block, lds, stream, args);
     return hipGetLastError();
 }
-static hipError_t launch_chain_skew_lev(const KArgs &args, uint32_t n_items, hipStream_t stream) {
-    const dim3 grid(n_items * (64 / kSlPairs)), block(64 * kSlWaves);
-    const size_t lds = sizeof(SlShared);
+typedef void (*SkKernel)(KArgs);
+template <bool EQO>
+static hipError_t launch_chain_skew_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     static bool attr_set[kMaxDevices] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = kMaxDevices - 1;
-    if (!attr_set[dev] || dev == kMaxDevices - 1) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew_lev<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew_lev<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew_lev<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&chain_kernel_skew_lev<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set[dev] = true;
-    }
-    const bool p24 = args.bit_depth == 24;
-    if (args.fma) { if (p24) hipLaunchKernelGGL((chain_kernel_skew_lev<true, true>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew_lev<true, false>), grid, block, lds, stream, args); }
-    else { if (p24) hipLaunchKernelGGL((chain_kernel_skew_lev<false, true>), grid, block, lds, stream, args); else hipLaunchKernelGGL((chain_kernel_skew_lev<false, false>), grid, block, lds, stream, args); }
-    return hipGetLastError();
+    static const SkKernel k[8] = {chain_kernel_skew<false, false, EQO, false>, chain_kernel_skew<false, false, EQO, true>, chain_kernel_skew<false, true, EQO, false>, chain_kernel_skew<false, true, EQO, true>,
+                                  chain_kernel_skew<true, false, EQO, false>, chain_kernel_skew<true, false, EQO, true>, chain_kernel_skew<true, true, EQO, false>, chain_kernel_skew<true, true, EQO, true>};
+    return sk_launch(args, dim3(n_items * (64 / SkCfg<EQO>::pairs)), dim3(64 * kSkWaves), sizeof(SkShared<EQO>), stream, attr_set, k);
+}
+static hipError_t launch_chain_skew_lev(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    static bool attr_set[kMaxDevices] = {};
+    static const SkKernel k[8] = {chain_kernel_skew_lev<false, false, false>, chain_kernel_skew_lev<false, false, true>, chain_kernel_skew_lev<false, true, false>, chain_kernel_skew_lev<false, true, true>,
+                                  chain_kernel_skew_lev<true, false, false>, chain_kernel_skew_lev<true, false, true>, chain_kernel_skew_lev<true, true, false>, chain_kernel_skew_lev<true, true, true>};
+    return sk_launch(args, dim3(n_items * (64 / kSlPairs)), dim3(64 * kSlWaves), sizeof(SlShared), stream, attr_set, k);
 }
 hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream) {      // shape 1 / 2 / 3: dspi_capi.cpp skew_class
     if (shape == 3) return launch_chain_skew_lev(args, n_items, stream);
