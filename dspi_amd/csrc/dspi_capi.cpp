@@ -409,13 +409,21 @@ int rebuild_launch_lists(dspi_ctx *c) {
         if (h_cls) pairs[h_cls]++;
         bool take[4] = {false, false, false, false};
         for (int cls = 1; cls <= 3; cls++) take[cls] = pairs[cls] > 0 && pairs[cls] <= skew_pair_limit(c->device, cls);
+        // a latency-layout item is ONE workgroup: a row's item is cut into its non-empty parts (8 or 2 stream pairs each), the part rides in
+        // the image field's top bits (kSkPartShift = 26, dspi_chain_skew.inc); mask / mask1 = the lanes whose first / second stream take part
+        auto push_parts = [&](std::vector<WgItem> &dst, uint32_t row, uint32_t image, uint64_t m0, uint64_t m1, int cls) {
+            const uint32_t ppw = cls == 1 ? 8u : 2u;
+            for (uint32_t part = 0; part < 64u / ppw; part++)
+                if (((m0 | m1) >> (part * ppw)) & ((1ull << ppw) - 1ull)) dst.push_back(WgItem{row, image | (part << 26), m0, m1});
+        };
         for (int lev = 0; lev < 2; lev++) {
             auto &v = c->launch_items[lev][1];
             std::vector<WgItem> keep;
             for (const WgItem &it : v) {
                 const int cls = skew_class(c->image_sig[it.image]);
                 // (class 3 sits in the leveller-on lists: list 5 there is the third shape)
-                (take[cls] ? c->launch_items[lev][cls == 2 ? 6 : 5] : keep).push_back(it);
+                if (take[cls]) push_parts(c->launch_items[lev][cls == 2 ? 6 : 5], it.wg, it.image, it.mask, it.mask, cls);
+                else keep.push_back(it);
             }
             v.swap(keep);
         }
@@ -426,10 +434,11 @@ int rebuild_launch_lists(dspi_ctx *c) {
                     l2[i].mask &= ~(1ull << h_lane);
                     if (l2[i].mask == 0) l2.erase(l2.begin() + (long)i);
                     auto &dst = c->launch_items[h_cls == 3 ? 1 : 0][h_cls == 2 ? 6 : 5];
+                    const uint32_t ppw = h_cls == 1 ? 8u : 2u, h_part = h_lane / ppw;
                     bool merged = false;
-                    for (WgItem &d : dst) if (d.wg == h_row && d.image == h_img) { d.mask |= 1ull << h_lane; merged = true; break; }
+                    for (WgItem &d : dst) if (d.wg == h_row && d.image == (h_img | (h_part << 26))) { d.mask |= 1ull << h_lane; merged = true; break; }
                     if (!merged) {
-                        dst.push_back(WgItem{h_row, h_img, 1ull << h_lane, 0ull});
+                        dst.push_back(WgItem{h_row, h_img | (h_part << 26), 1ull << h_lane, 0ull});
                         std::stable_sort(dst.begin(), dst.end(), [](const WgItem &x, const WgItem &y) { return x.wg < y.wg; });
                     }
                     break;

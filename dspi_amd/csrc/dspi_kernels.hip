@@ -1646,13 +1646,13 @@ static hipError_t launch_chain_skew_t(const KArgs &args, uint32_t n_items, hipSt
     static bool attr_set[kMaxDevices] = {};
     static const SkKernel k[8] = {chain_kernel_skew<false, false, EQO, false>, chain_kernel_skew<false, false, EQO, true>, chain_kernel_skew<false, true, EQO, false>, chain_kernel_skew<false, true, EQO, true>,
                                   chain_kernel_skew<true, false, EQO, false>, chain_kernel_skew<true, false, EQO, true>, chain_kernel_skew<true, true, EQO, false>, chain_kernel_skew<true, true, EQO, true>};
-    return sk_launch(args, dim3(n_items * (64 / SkCfg<EQO>::pairs)), dim3(64 * kSkWaves), sizeof(SkShared<EQO>), stream, attr_set, k);
+    return sk_launch(args, dim3(n_items), dim3(64 * kSkWaves), sizeof(SkShared<EQO>), stream, attr_set, k);
 }
 static hipError_t launch_chain_skew_lev(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     static bool attr_set[kMaxDevices] = {};
     static const SkKernel k[8] = {chain_kernel_skew_lev<false, false, false>, chain_kernel_skew_lev<false, false, true>, chain_kernel_skew_lev<false, true, false>, chain_kernel_skew_lev<false, true, true>,
                                   chain_kernel_skew_lev<true, false, false>, chain_kernel_skew_lev<true, false, true>, chain_kernel_skew_lev<true, true, false>, chain_kernel_skew_lev<true, true, true>};
-    return sk_launch(args, dim3(n_items * (64 / kSlPairs)), dim3(64 * kSlWaves), sizeof(SlShared), stream, attr_set, k);
+    return sk_launch(args, dim3(n_items), dim3(64 * kSlWaves), sizeof(SlShared), stream, attr_set, k);
 }
 hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream) {      // shape 1 / 2 / 3: dspi_capi.cpp skew_class
     if (shape == 3) return launch_chain_skew_lev(args, n_items, stream);

@@ -760,7 +760,7 @@ def test_full_size_config2_latency_layout(two_b):
         torch.cuda.synchronize()
         d.process_device(pcm.data_ptr(), blocks, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), enabled_only=True); d.sync()
         plan = d.launch_plan()
-        assert plan["latency_layout"] == S // 128 and plan["packed_shared"] == 0, plan      # (work items are rows of 128 streams: eight workgroups each)
+        assert plan["latency_layout"] == S // 16 and plan["packed_shared"] == 0, plan      # (one work item per workgroup of eight stream pairs)
         pv, kv = pairs.view(groups, R, 4, frames, 2), peaks.view(groups, R, blocks, 11)
         assert bool((pv[:, :, 0] == pv[0:1, :, 0]).all()), f"launch {c}: a workgroup's words differ from workgroup 0"
         assert bool((kv == kv[0:1]).all()), f"launch {c}: a workgroup's peaks differ from workgroup 0"
