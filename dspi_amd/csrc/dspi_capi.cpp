@@ -409,6 +409,32 @@ int rebuild_launch_lists(dspi_ctx *c) {
         if (h_cls) pairs[h_cls]++;
         bool take[4] = {false, false, false, false};
         for (int cls = 1; cls <= 3; cls++) take[cls] = pairs[cls] > 0 && pairs[cls] <= skew_pair_limit(c->device, cls);
+        // The whole context small — every (lane, image) slot of every class within its limit: EVERY float lane takes the latency layout,
+        // whatever the presets.  A lane whose two streams carry different images runs twice, once per image with the other half inactive
+        // (the kernels store per half): no per-lane-value tiles, no one-stream kernel, any mix of structures.
+        {
+            uint64_t slots[4] = {0, 0, 0, 0};
+            for (size_t i = 0; i < c->images.size(); i++)
+                if (c->image_refs[i] > 0)
+                    for (const WgItem &it : c->image_items[0][i]) slots[skew_class(c->image_sig[i])] += (uint64_t)__builtin_popcountll(it.mask | it.mask1);
+            bool all_small = slots[1] + slots[2] + slots[3] > 0;
+            for (int cls = 1; cls <= 3; cls++) if (slots[cls] > skew_pair_limit(c->device, cls)) all_small = false;
+            if (all_small) {
+                for (int lev = 0; lev < 2; lev++) for (int k = 1; k <= 4; k++) c->launch_items[lev][k].clear();
+                for (size_t i = 0; i < c->images.size(); i++) {
+                    if (c->image_refs[i] == 0) continue;
+                    const int cls = skew_class(c->image_sig[i]);
+                    auto &dst = c->launch_items[cls == 3 ? 1 : 0][cls == 2 ? 6 : 5];
+                    for (const WgItem &it : c->image_items[0][i])
+                        for (uint32_t ppw = cls == 1 ? 8u : 2u, part = 0; part < 64u / ppw; part++)
+                            if (((it.mask | it.mask1) >> (part * ppw)) & ((1ull << ppw) - 1ull)) dst.push_back(WgItem{it.wg, (uint32_t)i | (part << 26), it.mask, it.mask1});
+                }
+                for (int lev = 0; lev < 2; lev++)
+                    for (int k = 5; k <= 6; k++)
+                        std::stable_sort(c->launch_items[lev][k].begin(), c->launch_items[lev][k].end(), [](const WgItem &x, const WgItem &y) { return x.wg < y.wg; });
+                take[1] = take[2] = take[3] = false;      // (nothing left for the shared-preset rule below)
+            }
+        }
         // a latency-layout item is ONE workgroup: a row's item is cut into its non-empty parts (8 or 2 stream pairs each), the part rides in
         // the image field's top bits (kSkPartShift = 26, dspi_chain_skew.inc); mask / mask1 = the lanes whose first / second stream take part
         auto push_parts = [&](std::vector<WgItem> &dst, uint32_t row, uint32_t image, uint64_t m0, uint64_t m1, int cls) {

@@ -21,6 +21,16 @@ GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "go
 FLAVORS_WITH_KERNEL = (1, W.F32_FMA, 0)
 
 
+def on_latency_layout() -> bool:
+    """The run of a `both_layouts` test that pins the latency layout (conftest._layout)."""
+    return os.environ.get("DSPI_F32_LAYOUT") == "skew"
+
+
+def latency_plan(plan) -> bool:
+    """Every float lane on the latency layout: nothing left for the packed, per-lane-value or one-stream kernels."""
+    return plan["latency_layout"] > 0 and plan["packed_shared"] == plan["packed_per_lane_values"] == plan["packed_per_lane_values_and_bands"] == plan["one_stream_per_lane_images"] == 0
+
+
 def oracle_run(flavor, fs, vol, blob, data, blocks, B, depth, setup=None):
     o = Oracle(flavor, detmath=True)
     assert o.set_rate(fs) == 0
@@ -252,8 +262,8 @@ def test_enabled_only_leaves_silent_outputs_unwritten(monkeypatch):
 
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
 def test_latency_layout_mixed_with_other_kernels(flavor, monkeypatch):
-    """One context, three kernels in a call: most stream pairs share the latency-class preset (latency layout), a few streams get presets
-    of their own (per-lane kernels), and one group gets the leveller switched on (packed kernel).  Then the shared preset changes class
+    """One context on the latency layout with lanes of every kind: most stream pairs share the latency-class preset, two streams carry presets
+    of their own — their lanes run twice, once per image, each time with the other half inactive.  Then the shared preset changes class
     twice, mid-stream, on the same state arrays: an output EQ band becomes active (the latency layout's second shape: output rows), then
     the leveller is switched on (its third shape); tiled words."""
     monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
@@ -266,7 +276,7 @@ def test_latency_layout_mixed_with_other_kernels(flavor, monkeypatch):
     pcm = WL.synth_pcm16(S, B * blocks * 3, fs)
     o1 = d.process_host(np.ascontiguousarray(pcm[:, :B * blocks]), blocks, B, tiled=True)
     plan = d.launch_plan()
-    assert plan["latency_layout"] > 0 and plan["packed_per_lane_values"] + plan["one_stream_per_lane_images"] > 0, plan      # rows 0-1: per-lane values, row 2: latency layout
+    assert latency_plan(plan), plan      # streams 5 and 130 as half-active pairs of their own images, their lane partners 4 and 131 likewise on the common one
     p1, s1 = d.untile(o1[0], o1[1])
     # class change for everyone: output 1 gets a live EQ band -> output rows from here on
     eq = struct.pack("<BBBBfff", 3, 2, W.FILTER_PEAKING, 0, 900.0, 1.2, 4.0)
@@ -405,6 +415,7 @@ def test_vendor_requests_between_launches(flavor):
     d.close()
 
 
+@pytest.mark.both_layouts
 def test_per_stream_presets_and_clip_flags():
     """Copy-on-write images: streams with different presets in one workgroup (lane-masked launches)."""
     fs, B, S = 48000, 48, 70
@@ -423,7 +434,8 @@ def test_per_stream_presets_and_clip_flags():
         assert np.array_equal(rp, pairs[s]) and np.array_equal(rs, sub[s]) and np.array_equal(rk, peaks[s]), s
         assert o[s].status() == d.status(s)
     plan = d.launch_plan()      # 70 streams = one row of five images that differ in a preamp: the packed kernel with per-lane values, shared filters
-    assert plan["packed_per_lane_values"] == 1 and plan["packed_shared"] == 0 and plan["one_stream_per_lane_images"] == 0, plan
+    if on_latency_layout(): assert latency_plan(plan), plan      # (every (lane, image) pair a workgroup slot of its own, per-half stores)
+    else: assert plan["packed_per_lane_values"] == 1 and plan["packed_shared"] == 0 and plan["one_stream_per_lane_images"] == 0, plan
     flags = int.from_bytes(d.status(19)[-2:], "little")          # stream class 19 = full-scale square
     assert flags != 0 and d.clear_clips(19) == flags and int.from_bytes(d.status(19)[-2:], "little") == 0
     assert int.from_bytes(d.status(18)[-2:], "little") == int.from_bytes(o[18].status()[-2:], "little")
@@ -435,6 +447,7 @@ def test_per_stream_presets_and_clip_flags():
     d.close()
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_many_presets_one_process_call(flavor):
     """Dozens of parameter images in one context (every third stream its own preamp, some with the leveller off, some
@@ -462,6 +475,7 @@ def test_many_presets_one_process_call(flavor):
     d.close()
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("fma", [False, True])
 @pytest.mark.parametrize("fs,B,depth,S,lev", [(96000, 96, 16, 300, 1), (44100, 45, 24, 131, 1), (48000, 48, 16, 140, 0), (44100, 44, 16, 70, 0)])
 def test_one_structure_different_numbers(fma, fs, B, depth, S, lev):
@@ -523,7 +537,8 @@ def test_one_structure_different_numbers(fma, fs, B, depth, S, lev):
         rows = (S + 127) // 128
         # row 0 holds the stream of another structure: it runs on the one-stream kernel; every other row is a per-lane-value row with
         # per-lane filters; an odd last stream adds one more one-stream item
-        assert plan["packed_per_lane_values_and_bands"] == rows - 1 and plan["one_stream_per_lane_images"] >= 1 and plan["packed_shared"] == 0, plan
+        if on_latency_layout(): assert latency_plan(plan), plan
+        else: assert plan["packed_per_lane_values_and_bands"] == rows - 1 and plan["one_stream_per_lane_images"] >= 1 and plan["packed_shared"] == 0, plan
         for s_ in range(S):
             rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B, depth)
             assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (call, s_)
@@ -531,6 +546,7 @@ def test_one_structure_different_numbers(fma, fs, B, depth, S, lev):
     d.close()
 
 
+@pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor,fs,B,depth,S", [(1, 48000, 48, 16, 200), (1, 44100, 45, 24, 70), (0, 48000, 48, 16, 150), (0, 44100, 44, 24, 70)])
 def test_every_stream_its_own_preset(flavor, fs, B, depth, S):
     """every stream (both flavours) carries a different preset — different band kinds at the same band index (SVF
@@ -572,7 +588,8 @@ def test_every_stream_its_own_preset(flavor, fs, B, depth, S):
     # image, the rows return to the shared-parameter kernels — with the preset mutes, state resets and the delay lines of each
     # stream's own history
     plan = d.launch_plan()
-    assert plan["packed_shared"] == 0 and plan["q28_shared"] == 0 and plan["one_stream_per_lane_images"] > 0, plan
+    if flavor and on_latency_layout(): assert latency_plan(plan), plan
+    else: assert plan["packed_shared"] == 0 and plan["q28_shared"] == 0 and plan["one_stream_per_lane_images"] > 0, plan
     blob2 = WL.full_chain_blob(flavor); blob2["preamp"]["preamp_db"][0] = -4.5
     assert d.image_count() == S
     d.factory_defaults(); assert d.load_bulk(blob2) == 0
@@ -584,7 +601,8 @@ def test_every_stream_its_own_preset(flavor, fs, B, depth, S):
     pairs, sub, peaks = d.process_host(data, blocks, B, depth)
     plan = d.launch_plan()
     rows = (S + (127 if flavor else 63)) // (128 if flavor else 64)
-    if flavor: assert plan["packed_shared"] == rows and plan["packed_per_lane_values_and_bands"] == plan["packed_per_lane_values"] == 0 and plan["one_stream_per_lane_images"] == S % 2, plan
+    if flavor and on_latency_layout(): assert latency_plan(plan), plan
+    elif flavor: assert plan["packed_shared"] == rows and plan["packed_per_lane_values_and_bands"] == plan["packed_per_lane_values"] == 0 and plan["one_stream_per_lane_images"] == S % 2, plan
     else: assert plan["q28_shared"] == rows, plan
     for s_ in range(S):
         rp, rs, rk, _ = o[s_].process(data[s_], blocks, B, depth)
