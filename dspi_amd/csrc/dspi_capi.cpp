@@ -976,7 +976,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         for (int lev = 0; lev < 2 && all_latency; lev++)
             for (int k = 1; k <= 4; k++) if (!c->launch_items[lev][k].empty()) all_latency = false;
         if (!all_latency)
-            return fail(c, DSPI_E_UNSUPPORTED, "DSPI_OUT_SPDIF is served by the float chain's latency layout (shared presets, up to 2 048 streams): use dspi_spdif_encode after dspi_process here");
+            return fail(c, DSPI_E_UNSUPPORTED, "DSPI_OUT_SPDIF is served by the float chain's latency layout (small contexts): use dspi_spdif_encode after dspi_process here");
     }
     const size_t padded = (size_t)c->n_wg * c->sm.row;          // tiled buffers cover whole tiles
     const size_t pairs_b = tiled ? padded * (c->sm.n_out - 1) * frames * 4 : (size_t)c->n_streams * c->sm.n_pairs * frames * (spdif ? 16 : 8);

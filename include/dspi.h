@@ -93,7 +93,7 @@ extern "C" {
                                     *   pairs  uint32 [stream][pair][F][4]   {left lo, left hi, right lo, right hi}: TWICE the bytes of the word layout —
                                     * the words dspi_process + dspi_spdif_encode give, without the second pass (8 bytes in, 16 out per frame and pair).
                                     * The position in the 192-frame channel-status block runs on from call to call (dspi_spdif_block_pos).  Served by
-                                    * the float chain's latency layout (contexts of up to 2 048 streams, shared presets: its output waves hold both
+                                    * the float chain's latency layout (small contexts: up to 2 048 streams on a shared preset, 1 024 with presets of their own; its output waves hold both
                                     * sides of a pair of a frame in one lane and have time to spare); launches that run on other kernels return
                                     * DSPI_E_UNSUPPORTED — there the encoder would cost the chain 60 % more instructions and the
                                     * two-call sequence is the fast path.  Not with DSPI_OUT_TILED or DSPI_OUT_I2S_SLOTS. */
