@@ -83,6 +83,66 @@ class HipEvents:
         return float(ms.value)
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU while the timed region runs: a thread polling librocm_smi64 (ctypes, ~100 Hz).
+    The numbers go into the line as roofline.power_w / sclk_mhz (mean over the timed region) so that the claim "the kernel runs
+    into the board's power cap" is in the driver-run record and not only in a builder-side log.  Fails soft: no library, no
+    sensor -> the fields are null."""
+
+    class _Freq(ctypes.Structure):
+        _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32), ("frequency", ctypes.c_uint64 * 33)]
+
+    def __init__(self, device_index: int):
+        self.ok, self.samples, self._stop, self.cap_w = False, [], threading.Event(), None
+        self.dev = ctypes.c_uint32(device_index)
+        try:
+            self.smi = ctypes.CDLL("librocm_smi64.so")
+        except OSError:
+            try:
+                self.smi = ctypes.CDLL("/opt/rocm/lib/librocm_smi64.so")
+            except OSError:
+                return
+        try:
+            if self.smi.rsmi_init(ctypes.c_uint64(0)) != 0: return
+            cap = ctypes.c_uint64(0)
+            if self.smi.rsmi_dev_power_cap_get(self.dev, ctypes.c_uint32(0), ctypes.byref(cap)) == 0: self.cap_w = cap.value / 1e6
+            self.ok = self._read() is not None
+        except Exception:
+            self.ok = False
+
+    def _read(self):
+        pw = ctypes.c_uint64(0)
+        if self.smi.rsmi_dev_current_socket_power_get(self.dev, ctypes.byref(pw)) != 0:
+            if self.smi.rsmi_dev_power_ave_get(self.dev, ctypes.c_uint32(0), ctypes.byref(pw)) != 0: return None
+        f = PowerSampler._Freq()
+        mhz = None
+        if self.smi.rsmi_dev_gpu_clk_freq_get(self.dev, ctypes.c_int(0), ctypes.byref(f)) == 0 and f.current < 33:
+            mhz = f.frequency[f.current] / 1e6
+        return (time.perf_counter(), pw.value / 1e6, mhz)
+
+    def start(self):
+        if not self.ok: return
+        def loop():
+            while not self._stop.is_set():
+                r = self._read()
+                if r: self.samples.append(r)
+                time.sleep(0.008)
+        self.th = threading.Thread(target=loop, daemon=True)
+        self.th.start()
+
+    def stop(self):
+        if not self.ok: return
+        self._stop.set(); self.th.join()
+
+    def window(self, t0, t1):
+        """mean / max over the samples taken in [t0, t1] (perf_counter times); when the region is shorter than the sensor's
+        update period, the samples of its second half plus the first one after it."""
+        w = [x for x in self.samples if t0 + 0.5 * (t1 - t0) <= x[0] <= t1 + 0.02]
+        if not w: return None
+        pw = [x[1] for x in w]; ck = [x[2] for x in w if x[2]]
+        return {"power_w": sum(pw) / len(pw), "power_w_max": max(pw), "sclk_mhz": (sum(ck) / len(ck)) if ck else None, "power_cap_w": self.cap_w, "power_samples": len(w)}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1 only)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -238,8 +298,8 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="3", choices=["3", "2", "2b", "5", "perstream", "perstream_eq", "pdm", "spdif", "i2s"])
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (weak) or in total (strong); 0 = the config's own")
     ap.add_argument("--blocks-per-step", type=int, default=0, help="packets per dspi_process call; 0 = the config's own")
@@ -250,6 +310,7 @@ def main():
     ap.add_argument("--input", choices=["mix", "noise"], default="mix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="measure only the primary variant")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle check of the timed context (profiling runs)")
     args = ap.parse_args()
 
     # ---- N ranks without an external launcher: become the launcher ----
@@ -317,7 +378,9 @@ def timed_steps(args, torch, dist, backend, dev, ctx, step):
     ctx.sync()
     torch.cuda.synchronize()
     if dist: dist.barrier()
-    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    timed_steps.window = (t0, t1)
     kernel_ms = ev.elapsed_ms(e0, e1) / args.steps
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -340,19 +403,60 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
     _, N, _, P, _ = W.dims(flavor)
     pcm_cache = {}
 
-    def measure(contract, layout, inp):
+    def per_stream_requests(s):
+        """SURVEY 8f-1 workloads: the vendor requests that make stream s's preset its own (the same list for the context and for the checker)."""
+        import struct
+        reqs = []
+        if w.get("perstream"):
+            reqs.append((W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s)))
+            if w["perstream"] == "eq":
+                ch = int(os.environ.get("DSPI_BENCH_EQ_CH", "0"))      # which channel's first band differs per stream (0-1 master, 2.. outputs)
+                p = w["blob"]["eq"][ch][1]
+                reqs.append((W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, 1, int(p["type"]), 0, float(p["freq"]), float(p["q"]), 1.0 + 0.0001 * s)))
+        return reqs
+
+    def parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, launches, k=8):
+        """After the timed region, outside it: K sampled streams of the TIMED context — the words, sub words and peaks its last launch left in
+        the output buffers — against the CPU oracle replaying every launch the context has run (warm-up + timed steps, the same input buffer
+        each time, state carried from launch to launch).  The checker never touches the product path; a mismatch fails the run."""
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        cand = [0, 1, 14, (S // 3) // 20 * 20 + 16, (S // 2) // 20 * 20 + 18, (2 * S // 3) // 20 * 20 + 19, S - 2, S - 1]
+        sample = sorted({min(max(c, 0), S - 1) for c in cand})[:k]
+        R = ctx.tile_streams()
+        t0 = time.perf_counter()
+        for s in sample:
+            o = orclib.Oracle(flavor, detmath=True, fma=fma)
+            o.set_rate(FS); o.set_volume(w["vol"])
+            assert o.load_bulk(w["blob"]) == 0
+            for req, wv, pl in per_stream_requests(first + s): o.vendor_set(req, wv, pl)
+            x = pcm[s].cpu().numpy()
+            for _ in range(launches):
+                rp, rs, rk, _ = o.process(x, NB, B, 16)
+            if tiled:
+                gp = pairs[s // R, :, :, s % R].cpu().numpy().reshape(P, 2, frames).transpose(0, 2, 1)
+                gs = sub[s // R, :, s % R].cpu().numpy()
+            else:
+                gp, gs = pairs[s].cpu().numpy(), sub[s].cpu().numpy()
+            gk = peaks[s].cpu().numpy().view(np.uint16)
+            live = [pr for pr in range(P) if not w.get("enabled_only") or int(np.abs(rp[pr]).max()) > 0]      # (DSPI_OUT_ENABLED_ONLY: silent pairs stay unwritten)
+            if not all(np.array_equal(rp[pr], gp[pr]) for pr in live) or not np.array_equal(rk, gk) or \
+               not (np.array_equal(rs, gs) or (w.get("enabled_only") and int(np.abs(rs).max()) == 0)):
+                raise SystemExit(f"bench.py: PARITY FAILURE — stream {first + s} of the timed configuration differs from the oracle after {launches} launches")
+            if o.status() != ctx.status(s):
+                raise SystemExit(f"bench.py: PARITY FAILURE — status bytes of stream {first + s} differ from the oracle")
+            o.close() if hasattr(o, "close") else None
+        return {"parity_checked": len(sample), "parity_streams": [first + s for s in sample], "parity_launches_replayed": launches,
+                "parity_what": "every pair word, sub word, peak of the timed context's last launch + the status bytes, bit-exact vs the CPU oracle", "parity_s": time.perf_counter() - t0}
+
+    def measure(contract, layout, inp, check=False):
         fma = (contract == "fma") and flavor == 1
         ctx = Dspi(flavor, S, device=dev.index, fma=fma)
         ctx.set_rate(FS); ctx.set_volume(w["vol"])
         assert ctx.load_bulk(w["blob"]) == 0
         if w.get("perstream"):
-            import struct
             for s in range(S):
-                ctx.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s), stream=s)
-                if w["perstream"] == "eq":
-                    ch = int(os.environ.get("DSPI_BENCH_EQ_CH", "0"))      # which channel's first band differs per stream (0-1 master, 2.. outputs)
-                    p = w["blob"]["eq"][ch][1]
-                    ctx.vendor_set(W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, 1, int(p["type"]), 0, float(p["freq"]), float(p["q"]), 1.0 + 0.0001 * s), stream=s)
+                for req, wv, pl in per_stream_requests(first + s): ctx.vendor_set(req, wv, pl, stream=s)
         if inp not in pcm_cache:
             pcm_cache.clear()
             pcm_cache[inp] = synth_device(torch, dev, S, frames, FS, 1234 + rank, inp == "mix", first)
@@ -367,19 +471,27 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
             sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
         peaks = torch.empty((S, NB, 2 + N), dtype=torch.int16, device=dev)
         torch.cuda.synchronize()
+        smi = PowerSampler(dev.index) if check else None
+        if smi: smi.start()
         elapsed, kernel_ms = timed_steps(args, torch, dist, backend, dev, ctx,
                                          lambda: ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled,
                                                                     enabled_only=bool(w.get("enabled_only"))))
+        if smi: smi.stop()
         plan = ctx.launch_plan()
+        n_total = total if args.scaling == "strong" else total * world
+        fps = float(n_total) * frames * args.steps / elapsed
+        m = dict(contract=contract if flavor == 1 else "integer", out_layout=layout, input=inp, frames_per_s=fps, value=fps * CH,
+                 ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms, latency_layout=plan.get("latency_layout", 0) > 0)
+        if w.get("enabled_only"): m["enabled_only"] = True      # (silent pairs and the sub are not zero-filled: fewer bytes than the firmware's own stores)
+        if smi: m["power"] = smi.window(*timed_steps.window) if smi.ok else None
+        if check and rank == 0 and not args.no_parity:
+            m["parity"] = parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, args.warmup + args.steps)
         ctx.close()
         del pairs, sub, peaks
         torch.cuda.empty_cache()
-        n_total = total if args.scaling == "strong" else total * world
-        fps = float(n_total) * frames * args.steps / elapsed
-        return dict(contract=contract if flavor == 1 else "integer", out_layout=layout, input=inp, frames_per_s=fps, value=fps * CH,
-                    ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms, latency_layout=plan.get("latency_layout", 0) > 0)
+        return m
 
-    primary = measure(args.contract, args.out_layout, args.input)
+    primary = measure(args.contract, args.out_layout, args.input, check=True)
     also = []
     if world == 1 and not args.no_variants:
         other_contract = [("canonical" if args.contract == "fma" else "fma")] if flavor == 1 else []
@@ -409,9 +521,24 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
              "traffic_stale": (prof.get("src_sha16") != SRC_SHA16) if prof else None,
              "hbm_fraction_measured_traffic": (prof["hbm_bytes_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof else None,
              "valu_fraction": (prof["valu_insts_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS) if prof and prof["valu_insts_per_frame"] else None,
-             "binds": "valu"}
-        # what binds: the bytes actually moved (profiles/) against the practical ceiling of this memory system (~6 TB/s), else issue
-        if r["hbm_fraction_measured_traffic"] and r["hbm_fraction_measured_traffic"] >= 0.70: r["binds"] = "memory (bytes moved at the L2-fabric boundary)"
+             "binds": None}
+        # evidence for what binds: socket power and shader clock sampled over the timed region, the instruction
+        # issue fraction at THAT clock (a SIMD issues one wave-instruction per 4 cycles), and the bytes moved against the ~6 TB/s this
+        # memory system sustains in practice
+        pw = m.get("power")
+        if pw:
+            r.update(power_w=pw["power_w"], power_w_max=pw["power_w_max"], power_cap_w=pw["power_cap_w"], sclk_mhz=pw["sclk_mhz"], power_samples=pw["power_samples"])
+            if pw["sclk_mhz"] and prof and prof["valu_insts_per_frame"]:
+                r["valu_fraction_at_sclk"] = prof["valu_insts_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / (1024 * pw["sclk_mhz"] * 1e6 / 4.0)
+        else:
+            r.update(power_w=None, sclk_mhz=None)
+        at_cap = bool(pw and pw["power_cap_w"] and pw["power_w_max"] >= 0.95 * pw["power_cap_w"])
+        issue = r.get("valu_fraction_at_sclk") or r["valu_fraction"]
+        mem = r["hbm_fraction_measured_traffic"]
+        if at_cap: r["binds"] = "power cap: the clock is held below its free-running value, time follows energy per frame (VALU issue %s of the capped clock's slots, %s of 8 TB/s moved)" % (("%.2f" % issue) if issue else "n/a", ("%.2f" % mem) if mem else "n/a")
+        elif issue and issue >= 0.60 and (not mem or issue >= mem): r["binds"] = "valu issue"
+        elif mem and mem >= 0.70: r["binds"] = "memory (bytes moved at the L2-fabric boundary)"
+        else: r["binds"] = "latency (neither issue slots nor bytes near their ceilings)"
         return r
 
     if flavor == 1:
@@ -449,6 +576,9 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
                    "frames_per_s": primary["frames_per_s"], "realtime_streams": primary["frames_per_s"] / FS, "parallelism": f"streams sharded x{world}"},
         "roofline": roofline,
     }
+    if primary.get("parity"): out.update(primary["parity"])
+    else: out["parity_checked"] = 0
+    if primary.get("enabled_only"): out["config"]["enabled_only"] = "DSPI_OUT_ENABLED_ONLY: silent pairs and the sub are left unwritten (the firmware zero-fills them, usb_audio.c:930-933)"
     if also:
         out["also"] = also
     if world == 1 and not args.no_cpu_baseline:

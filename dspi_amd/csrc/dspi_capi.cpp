@@ -84,6 +84,8 @@ struct dspi_ctx {
     int32_t *d_pairs = nullptr; size_t d_pairs_cap = 0;
     int32_t *d_sub = nullptr; size_t d_sub_cap = 0;
     uint16_t *d_peaks = nullptr; size_t d_peaks_cap = 0;
+    uint16_t *d_clip = nullptr; size_t d_clip_cap = 0;          // DSPI_OUT_CLIP_FLAGS on host buffers
+    int32_t *d_spdif_words = nullptr; size_t d_spdif_words_cap = 0;      // DSPI_OUT_SPDIF on launches the latency layout does not serve: the chain's pair words of one row chunk
     // PDM sub output (dspi_pdm.hip): modulator state per stream, allocated on first use; staging for host buffers
     uint32_t *d_pdm = nullptr;
     int32_t *d_pdm_in = nullptr; size_t d_pdm_in_cap = 0;
@@ -684,7 +686,7 @@ void dspi_destroy(dspi_ctx *c) {
         (void)hipSetDevice(c->device);
         if (c->hs) (void)hipStreamSynchronize(c->hs);
         for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_xwords, (void *)c->d_vals, (void *)c->d_pv_rows, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_stream_image, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
-                        (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks})
+                        (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks, (void *)c->d_clip, (void *)c->d_spdif_words})
             if (p) (void)hipFree(p);
         for (hipEvent_t e : c->pipe_events) (void)hipEventDestroy(e);
         if (c->hs_in) (void)hipStreamDestroy(c->hs_in);
@@ -904,8 +906,17 @@ int dspi_spdif_encode(dspi_ctx *c, const int32_t *pairs, uint32_t n_frames, uint
         HIPCK(c, hipMemcpyAsync(c->d_spdif_in, pairs, in_b, hipMemcpyHostToDevice, c->hs));
         d_in = c->d_spdif_in; d_out = c->d_spdif_out;
     }
+    // the sample-rate byte of the channel status is each device's own (audio_spdif.c:250-256): one word for everybody while every live
+    // image runs at one rate, else per stream from the committed images
     const uint32_t fs = readable(c, DSPI_ALL_STREAMS).freq;
-    HIPCK(c, launch_spdif(tiled, d_in, d_out, c->n_streams, (uint32_t)c->sm.n_pairs, n_frames, (uint32_t)c->sm.row, c->n_wg, block_pos, fs, c->hs));
+    bool one_rate = true;
+    for (size_t i = 0; i < c->images.size(); i++) if (c->image_refs[i] > 0 && c->images[i]->freq != fs) one_rate = false;
+    SpdifRates rates{nullptr, nullptr, 0u};
+    if (!one_rate) {
+        if ((rc = commit_params(c))) return rc;
+        rates = SpdifRates{c->d_images, c->d_stream_image, 0u};
+    }
+    HIPCK(c, launch_spdif(tiled, d_in, d_out, c->n_streams, (uint32_t)c->sm.n_pairs, n_frames, (uint32_t)c->sm.row, c->n_wg, block_pos, fs, rates, c->hs));
     if (!dev) {
         HIPCK(c, hipMemcpyAsync(subframes, c->d_spdif_out, out_b, hipMemcpyDeviceToHost, c->hs));
         HIPCK(c, hipStreamSynchronize(c->hs));
@@ -969,20 +980,24 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     const size_t in_b = (size_t)c->n_streams * frames * (bit_depth == 24 ? 6 : 4);
     const bool tiled = flags & DSPI_OUT_TILED;
     const bool spdif = flags & DSPI_OUT_SPDIF;
+    bool spdif_two_pass = false;
     if (spdif) {
         if (tiled || (flags & DSPI_OUT_I2S_SLOTS)) return fail(c, DSPI_E_INVAL, "DSPI_OUT_SPDIF goes with neither DSPI_OUT_TILED nor DSPI_OUT_I2S_SLOTS");
-        // only the latency layout's output waves encode subframes: every lane of the launch must be on it
+        // The latency layout's output waves encode the subframes themselves.  A launch with lanes on any other kernel (the flag is a
+        // property of the output, not of the stream count) runs the chain into a scratch buffer of pair words, row chunk by row chunk,
+        // and the subframe encoder from there into `pairs`: the same words, the block position carried the same way.
         bool all_latency = c->flavor != 0;
         for (int lev = 0; lev < 2 && all_latency; lev++)
             for (int k = 1; k <= 4; k++) if (!c->launch_items[lev][k].empty()) all_latency = false;
-        if (!all_latency)
-            return fail(c, DSPI_E_UNSUPPORTED, "DSPI_OUT_SPDIF is served by the float chain's latency layout (small contexts): use dspi_spdif_encode after dspi_process here");
+        spdif_two_pass = !all_latency && out->pairs != nullptr;
     }
     const size_t padded = (size_t)c->n_wg * c->sm.row;          // tiled buffers cover whole tiles
     const size_t pairs_b = tiled ? padded * (c->sm.n_out - 1) * frames * 4 : (size_t)c->n_streams * c->sm.n_pairs * frames * (spdif ? 16 : 8);
     const size_t sub_b = (tiled ? padded : (size_t)c->n_streams) * frames * 4;
     const size_t peaks_b = (size_t)c->n_streams * n_blocks * c->sm.n_ch * 2;
     const bool dev = flags & DSPI_MEM_DEVICE;
+    // DSPI_OUT_CLIP_FLAGS: the caller's dspi_out has the ABI-7 member `clip_flags`
+    uint16_t *const clip_out = (flags & DSPI_OUT_CLIP_FLAGS) ? out->clip_flags : nullptr;
 
     KArgs a{};
     a.state = c->d_state; a.dlines = c->d_dlines; a.ring = c->d_ring;
@@ -991,11 +1006,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.fma = c->fma ? 1u : 0u;
     a.skip_silent = (flags & DSPI_OUT_ENABLED_ONLY) ? 1u : 0u;
     a.i2s_slots = (flags & DSPI_OUT_I2S_SLOTS) ? 1u : 0u;
-    if (spdif) {
-        a.spdif = 1u; a.spdif_pos = c->spdif_pos;
-        spdif_status_words(readable(c, DSPI_ALL_STREAMS).freq, a.spdif_lo, a.spdif_hi);
-        c->spdif_pos = (uint32_t)((c->spdif_pos + frames) % 192u);
-    }
+    if (spdif) { a.spdif = spdif_two_pass ? 0u : 1u; a.spdif_pos = c->spdif_pos; }
     if (c->flavor && !tiled && (out->pairs || out->sub)) {      // stream-major words of the packed kernel go through its exchange area
         const size_t xb = (size_t)c->n_wg * 2 * kMaxOut * kChunk * c->sm.row * 4;
         if ((rc = ensure(c, c->d_xwords, c->d_xwords_cap, xb))) return rc;
@@ -1009,6 +1020,21 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         if (out->pairs) { if ((rc = ensure(c, c->d_pairs, c->d_pairs_cap, pairs_b))) return rc; a.pairs = c->d_pairs; }
         if (out->sub) { if ((rc = ensure(c, c->d_sub, c->d_sub_cap, sub_b))) return rc; a.sub = c->d_sub; }
         if (out->peaks) { if ((rc = ensure(c, c->d_peaks, c->d_peaks_cap, peaks_b))) return rc; a.peaks = c->d_peaks; }
+        if (clip_out && (rc = ensure(c, c->d_clip, c->d_clip_cap, (size_t)c->n_streams * 2))) return rc;
+        // DSPI_OUT_ENABLED_ONLY leaves the silent parts of pairs / sub unwritten: the staging buffers are copied back whole, so what the
+        // caller finds there is zeros (the firmware's own fill), not stale staging memory
+        if (flags & DSPI_OUT_ENABLED_ONLY) {
+            if (a.pairs) HIPCK(c, hipMemsetAsync(a.pairs, 0, pairs_b, c->hs));
+            if (a.sub) HIPCK(c, hipMemsetAsync(a.sub, 0, sub_b, c->hs));
+        }
+    }
+    int32_t *const final_pairs = a.pairs;      // where the caller's pair words / subframes end up (device side)
+    uint32_t two_pass_rows = 0;
+    if (spdif_two_pass) {
+        // scratch for the chain's pair words of a row chunk: at least one workgroup per CU, at most ~1 GiB
+        const size_t row_b = (size_t)c->sm.row * c->sm.n_pairs * frames * 8;
+        two_pass_rows = (uint32_t)std::min<size_t>(c->n_wg, std::max<size_t>(256, (size_t)(1u << 30) / row_b));
+        if ((rc = ensure(c, c->d_spdif_words, c->d_spdif_words_cap, (size_t)two_pass_rows * row_b))) return rc;
     }
     a.img = c->d_images;
     a.stream_image = c->d_stream_image;
@@ -1022,7 +1048,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     const int nl = c->flavor ? 6 : 2;
     a.vals = c->d_vals;
     // the chain launches for the rows [r0, r1) (the lists are sorted by row)
-    auto launch_rows = [&](uint32_t r0, uint32_t r1) -> int {
+    auto launch_rows_1 = [&](uint32_t r0, uint32_t r1) -> int {
         for (int lev = 0; lev < 2; lev++)
             for (int l = 0; l < nl; l++) {
                 const auto &items = c->launch_items[lev][ls[l].list];
@@ -1038,7 +1064,33 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
             }
         return 0;
     };
-    if (dev) return launch_rows(0, c->n_wg);
+    const uint32_t row_ = (uint32_t)c->sm.row;
+    auto launch_rows = [&](uint32_t r0, uint32_t r1) -> int {
+        if (!spdif_two_pass) return launch_rows_1(r0, r1);
+        const size_t per_stream = (size_t)c->sm.n_pairs * frames;      // frames of pair words per stream
+        for (uint32_t q0 = r0; q0 < r1; q0 += two_pass_rows) {
+            const uint32_t q1 = std::min(r1, q0 + two_pass_rows);
+            const size_t s0 = (size_t)q0 * row_, s1 = std::min((size_t)q1 * row_, (size_t)c->n_streams);
+            a.pairs = c->d_spdif_words - s0 * per_stream * 2;      // the kernels index by absolute stream: stream s0 lands at the scratch's start
+            int r = launch_rows_1(q0, q1);
+            if (r) return r;
+            hipError_t e = launch_spdif(false, c->d_spdif_words, reinterpret_cast<uint32_t *>(final_pairs) + s0 * per_stream * 4, (uint32_t)(s1 - s0), (uint32_t)c->sm.n_pairs,
+                                        (uint32_t)frames, row_, q1 - q0, c->spdif_pos, 0u, SpdifRates{c->d_images, c->d_stream_image, (uint32_t)s0}, c->hs);
+            if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("spdif encoder launch: ") + hipGetErrorString(e));
+        }
+        return 0;
+    };
+    // sticky clip flags of every stream (global_status.clip_flags, usb_audio.c:2427-2443), after the chain on the same stream
+    auto gather_clip = [&](uint16_t *dst) -> int {
+        hipError_t e = launch_clip_gather(c->d_state, c->n_streams, row_, (uint32_t)c->sm.n_slots, (uint32_t)c->sm.clip, dst, c->hs);
+        return e == hipSuccess ? 0 : fail(c, DSPI_E_HIP, std::string("clip gather launch: ") + hipGetErrorString(e));
+    };
+    if (dev) {
+        if ((rc = launch_rows(0, c->n_wg))) return rc;
+        if (clip_out && (rc = gather_clip(clip_out))) return rc;
+        if (spdif) c->spdif_pos = (uint32_t)((c->spdif_pos + frames) % 192u);      // only once everything is enqueued: a failed call leaves the block position alone
+        return DSPI_OK;
+    }
 
     // ---- host buffers (the caller of usb_audio.c:1326-1332 is a host feeding packets): staged through device buffers.  The link moves
     // 4 + 36 bytes per frame, the chain 100 times that, so the call is link-bound; what can be saved is the serialisation: the rows are
@@ -1063,7 +1115,13 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
                 pins[i].on = hipHostRegister(pins[i].p, pin_b[i], hipHostRegisterDefault) == hipSuccess;
                 if (!pins[i].on) (void)hipGetLastError();
             }
-    auto unpin = [&]() { for (auto &pn : pins) if (pn.on) { (void)hipHostUnregister(pn.p); pn.on = false; } };
+    // (error paths too: no copy or kernel may still be in flight on memory that is about to be unregistered)
+    auto unpin = [&]() {
+        if (c->hs_in) (void)hipStreamSynchronize(c->hs_in);
+        (void)hipStreamSynchronize(c->hs);
+        if (c->hs_out) (void)hipStreamSynchronize(c->hs_out);
+        for (auto &pn : pins) if (pn.on) { (void)hipHostUnregister(pn.p); pn.on = false; }
+    };
     if (n_chunks > 1 && !c->hs_in) {
         if (hipStreamCreateWithFlags(&c->hs_in, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->hs_out, hipStreamNonBlocking) != hipSuccess) {
             unpin(); return fail(c, DSPI_E_HIP, "stream creation for the host-buffer pipeline failed");
@@ -1094,7 +1152,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         const size_t t0 = tiled ? (size_t)r0 * row : s0, t1 = tiled ? (size_t)r1 * row : s1;
         if (out->pairs) {
             const size_t per = tiled ? (size_t)(c->sm.n_out - 1) * frames * 4 : (size_t)c->sm.n_pairs * frames * (spdif ? 16 : 8);
-            if ((he = hipMemcpyAsync(reinterpret_cast<char *>(out->pairs) + t0 * per, reinterpret_cast<char *>(c->d_pairs) + t0 * per, (t1 - t0) * per, hipMemcpyDeviceToHost, sout)) != hipSuccess) return fail_hip(he, "D2H pairs");
+            if ((he = hipMemcpyAsync(reinterpret_cast<char *>(out->pairs) + t0 * per, reinterpret_cast<char *>(final_pairs) + t0 * per, (t1 - t0) * per, hipMemcpyDeviceToHost, sout)) != hipSuccess) return fail_hip(he, "D2H pairs");
         }
         if (out->sub) {
             const size_t per = frames * 4;
@@ -1105,12 +1163,17 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
             if ((he = hipMemcpyAsync(reinterpret_cast<char *>(out->peaks) + s0 * per, reinterpret_cast<char *>(c->d_peaks) + s0 * per, (s1 - s0) * per, hipMemcpyDeviceToHost, sout)) != hipSuccess) return fail_hip(he, "D2H peaks");
         }
     }
+    if (clip_out) {
+        if ((rc = gather_clip(c->d_clip))) { unpin(); return rc; }
+        if ((he = hipMemcpyAsync(clip_out, c->d_clip, (size_t)c->n_streams * 2, hipMemcpyDeviceToHost, c->hs)) != hipSuccess) return fail_hip(he, "D2H clip flags");
+    }
     if (n_chunks > 1) {
         if ((he = hipStreamSynchronize(c->hs_out)) != hipSuccess) return fail_hip(he, "sync");
         if ((he = hipStreamSynchronize(c->hs_in)) != hipSuccess) return fail_hip(he, "sync");
     }
     if ((he = hipStreamSynchronize(c->hs)) != hipSuccess) return fail_hip(he, "sync");
     unpin();
+    if (spdif) c->spdif_pos = (uint32_t)((c->spdif_pos + frames) % 192u);
     return DSPI_OK;
 }
 

@@ -27,7 +27,7 @@ struct KArgs {
     uint32_t skip_silent;    // DSPI_OUT_ENABLED_ONLY: sample words of silent outputs (a disabled S/PDIF pair, the sub while it is off) need not be stored
     uint32_t i2s_slots;      // DSPI_OUT_I2S_SLOTS: pairs whose slot is an I2S slot (DevImage::i2s_pairs) carry left-justified I2S words (word << 8)
     uint32_t spdif;          // DSPI_OUT_SPDIF (latency layout only): `pairs` takes IEC 60958 subframes, uint32 [stream][pair][frame][4]
-    uint32_t spdif_pos, spdif_lo, spdif_hi;      // position of the launch's first frame in the 192-frame block, channel status words
+    uint32_t spdif_pos;      // position of the launch's first frame in the 192-frame block (the channel status follows each image's own fs_hz)
     uint32_t fma;            // float flavour: the context's contract is DSPI_FLOAT_CONTRACT_FMA (selects the kernel family at launch)
 };
 
@@ -61,15 +61,16 @@ hipError_t launch_pdm(bool tiled, uint32_t *state, const int32_t *sub, uint32_t 
 hipError_t launch_pdm_reset(uint32_t *state, uint32_t n_streams, uint32_t row, uint32_t n_wg, int32_t only_stream, int init, hipStream_t stream);
 
 // ---- S/PDIF subframe encoder (dspi_spdif.hip)
-// IEC 60958-3 consumer channel status, 5 bytes (audio_spdif.c:83-89, sample-rate byte :250-256)
-static inline void spdif_status_words(uint32_t fs, uint32_t &lo, uint32_t &hi) {
-    const uint32_t rate = fs == 44100 ? 0x00u : fs == 48000 ? 0x02u : fs == 96000 ? 0x0Au : 0x01u;
-    lo = 0x04u | (rate << 24); hi = 0x0Bu;
-}
+// The sample-rate byte of the channel status (audio_spdif.c:250-256) is a property of the DEVICE: streams of one context may run at
+// different rates.  stream_image == nullptr: every stream at `fs`; else stream s reads img[stream_image[stream0 + s]].fs_hz.
+struct SpdifRates { const DevImage *img; const uint32_t *stream_image; uint32_t stream0; };
 hipError_t launch_spdif(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
-                        uint32_t n_wg, uint32_t block_pos, uint32_t fs, hipStream_t stream);
+                        uint32_t n_wg, uint32_t block_pos, uint32_t fs, const SpdifRates &rates, hipStream_t stream);
 // I2S slots (audio_i2s_multi.c:217-226): words << 8 for the pairs in pair_mask; same layouts as the pair words themselves
 hipError_t launch_i2s(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
                       uint32_t n_wg, uint32_t pair_mask, hipStream_t stream);
+
+// ---- status at scale (dspi_status.hip): out[s] = OR of stream s's four sticky clip slots (state slots clip_slot .. clip_slot + 3)
+hipError_t launch_clip_gather(const uint32_t *state, uint32_t n_streams, uint32_t row, uint32_t n_slots, uint32_t clip_slot, uint16_t *out, hipStream_t stream);
 
 }  // namespace dspi

@@ -204,7 +204,7 @@ void Params::boot() {
     rate_changed(freq);
     service();
     memset(&ops, 0, sizeof(ops));     // nothing has run yet: state starts zeroed by the context
-    // First boot on an erased flash writes the fresh directory (preset_boot_load -> dir_flush, flash_storage.c:1086-1090),
+    // First boot on an erased flash writes the fresh directory (preset_boot_load -> dir_flush, flash_storage.c:1097-1100),
     // and every flash_write_sector re-arms the preset mute for flash_mute_hold_samples() = max(10 ms, 512) samples at the
     // power-on rate of 44.1 kHz (:272-276, :347-348): a new device starts with 512 muted samples and the fade-in.  A device whose
     // flash already holds a directory writes nothing at boot and does not mute (DSPI_BOOT_POPULATED_FLASH, include/dspi.h).

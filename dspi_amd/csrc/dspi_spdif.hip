@@ -26,10 +26,11 @@ constexpr uint32_t kFrameSlice = 32;
 
 template <bool TILED>
 __global__ __launch_bounds__(128) void spdif_kernel(const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames,
-                                                     uint32_t row, uint32_t block_pos, uint32_t status_lo, uint32_t status_hi) {
+                                                     uint32_t row, uint32_t block_pos, uint32_t status_lo, uint32_t status_hi, SpdifRates rates) {
     const uint32_t wg = blockIdx.x, pair = blockIdx.y, col = threadIdx.x;
     const uint32_t stream = wg * row + col;
     if (col >= row || stream >= n_streams) return;
+    if (rates.stream_image) status_lo = spdif_status_lo(rates.img[rates.stream_image[rates.stream0 + stream]].fs_hz);
     const size_t F = n_frames;
     // tiled: outputs 2*pair and 2*pair+1 are separate [frame][R] planes; stream-major: interleaved [frame][2]
     const int32_t *inL = TILED ? pairs + ((size_t)wg * (2 * n_pairs) + 2 * pair) * F * row + col : pairs + ((size_t)stream * n_pairs + pair) * F * 2;
@@ -60,9 +61,10 @@ __global__ __launch_bounds__(128) void spdif_kernel(const int32_t *pairs, uint32
 // Stream-major buffers are contiguous in time per (stream, pair), and a frame's subframes depend on nothing but its own
 // words and its block position: one lane per FRAME here, so a wave reads 512 and writes 1024 contiguous bytes.
 __global__ __launch_bounds__(256) void spdif_kernel_frames(const int32_t *pairs, uint32_t *out, uint64_t total, uint32_t n_frames, uint32_t block_pos,
-                                                          uint32_t status_lo, uint32_t status_hi) {
+                                                          uint32_t status_lo, uint32_t status_hi, SpdifRates rates, uint32_t n_pairs) {
     const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;      // (stream * n_pairs + pair) * n_frames + frame
     if (idx >= total) return;
+    if (rates.stream_image) status_lo = spdif_status_lo(rates.img[rates.stream_image[rates.stream0 + (uint32_t)(idx / ((uint64_t)n_pairs * n_frames))]].fs_hz);
     const uint32_t f = (uint32_t)(idx % n_frames);
     const uint32_t pos = (block_pos + f) % 192u;
     const uint32_t wl = (uint32_t)pairs[idx * 2], wr = (uint32_t)pairs[idx * 2 + 1];
@@ -76,9 +78,10 @@ __global__ __launch_bounds__(256) void spdif_kernel_frames(const int32_t *pairs,
 
 // even frame counts: two frames per lane (16 bytes in, 32 bytes out)
 __global__ __launch_bounds__(256) void spdif_kernel_frames2(const int32_t *pairs, uint32_t *out, uint64_t total2, uint32_t half_frames, uint32_t block_pos,
-                                                           uint32_t status_lo, uint32_t status_hi) {
+                                                           uint32_t status_lo, uint32_t status_hi, SpdifRates rates, uint32_t n_pairs) {
     const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;      // (stream * n_pairs + pair) * (n_frames / 2) + frame pair
     if (idx >= total2) return;
+    if (rates.stream_image) status_lo = spdif_status_lo(rates.img[rates.stream_image[rates.stream0 + (uint32_t)(idx / ((uint64_t)n_pairs * half_frames))]].fs_hz);
     const uint32_t f = (uint32_t)(idx % half_frames) * 2u;
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     const u4 w = *reinterpret_cast<const u4 *>(pairs + idx * 4);
@@ -144,15 +147,15 @@ hipError_t launch_i2s(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t 
 }
 
 hipError_t launch_spdif(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t n_streams, uint32_t n_pairs, uint32_t n_frames, uint32_t row,
-                        uint32_t n_wg, uint32_t block_pos, uint32_t fs, hipStream_t stream) {
-    // IEC 60958-3 consumer channel status, 5 bytes (audio_spdif.c:83-89, sample-rate byte :250-256)
-    uint32_t lo, hi;
-    spdif_status_words(fs, lo, hi);
-    if (tiled) hipLaunchKernelGGL(spdif_kernel<true>, dim3(n_wg, n_pairs, (n_frames + kFrameSlice - 1) / kFrameSlice), dim3(128), 0, stream, pairs, out, n_streams, n_pairs, n_frames, row, block_pos, lo, hi);
+                        uint32_t n_wg, uint32_t block_pos, uint32_t fs, const SpdifRates &rates, hipStream_t stream) {
+    // IEC 60958-3 consumer channel status, 5 bytes (audio_spdif.c:83-89, sample-rate byte :250-256): of `fs` for every stream, or
+    // (rates.stream_image set) of each stream's own image
+    const uint32_t lo = spdif_status_lo(fs), hi = kSpdifStatusHi;
+    if (tiled) hipLaunchKernelGGL(spdif_kernel<true>, dim3(n_wg, n_pairs, (n_frames + kFrameSlice - 1) / kFrameSlice), dim3(128), 0, stream, pairs, out, n_streams, n_pairs, n_frames, row, block_pos, lo, hi, rates);
     else {
         const uint64_t total = (uint64_t)n_streams * n_pairs * n_frames;
-        if (n_frames % 2 == 0) hipLaunchKernelGGL(spdif_kernel_frames2, dim3((uint32_t)((total / 2 + 255) / 256)), dim3(256), 0, stream, pairs, out, total / 2, n_frames / 2, block_pos, lo, hi);
-        else hipLaunchKernelGGL(spdif_kernel_frames, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pairs, out, total, n_frames, block_pos, lo, hi);
+        if (n_frames % 2 == 0) hipLaunchKernelGGL(spdif_kernel_frames2, dim3((uint32_t)((total / 2 + 255) / 256)), dim3(256), 0, stream, pairs, out, total / 2, n_frames / 2, block_pos, lo, hi, rates, n_pairs);
+        else hipLaunchKernelGGL(spdif_kernel_frames, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, pairs, out, total, n_frames, block_pos, lo, hi, rates, n_pairs);
     }
     return hipGetLastError();
 }

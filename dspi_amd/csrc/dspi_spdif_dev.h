@@ -20,6 +20,12 @@ static __device__ __forceinline__ void subframe(uint32_t sample, uint32_t preamb
     p ^= (((ph & 0x2au) * 0x2au) >> 6) & 1u;
     h = ((s1 & 0xffffu) >> 8) | ((s2 & 0xffffu) << 8) | ((ph & 0x7fu) << 24) | (p << 31);
 }
+// IEC 60958-3 consumer channel status, first word (audio_spdif.c:83-89, sample-rate byte :250-256); the fifth byte is kSpdifStatusHi
+static __host__ __device__ __forceinline__ uint32_t spdif_status_lo(uint32_t fs) {
+    const uint32_t rate = fs == 44100 ? 0x00u : fs == 48000 ? 0x02u : fs == 96000 ? 0x0Au : 0x01u;
+    return 0x04u | (rate << 24);
+}
+constexpr uint32_t kSpdifStatusHi = 0x0Bu;
 // a frame's two subframes (left: preamble Z at the block start, else X; right: Y) with the channel-status bit of its block position
 // (40 bits, the rest zero: audio_spdif.c:91-94)
 typedef uint32_t spdif_u4 __attribute__((ext_vector_type(4)));

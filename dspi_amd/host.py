@@ -20,6 +20,7 @@ OUT_TILED = 0x2
 OUT_ENABLED_ONLY = 0x4
 OUT_I2S_SLOTS = 0x8
 OUT_SPDIF = 0x10
+OUT_CLIP_FLAGS = 0x20
 E_NODEVICE = -11
 E_UNSUPPORTED = -14
 
@@ -31,7 +32,7 @@ class DspiError(RuntimeError):
 
 
 class _Out(C.Structure):
-    _fields_ = [("pairs", C.c_void_p), ("sub", C.c_void_p), ("peaks", C.c_void_p)]
+    _fields_ = [("pairs", C.c_void_p), ("sub", C.c_void_p), ("peaks", C.c_void_p), ("clip_flags", C.c_void_p)]      # clip_flags: ABI 7, read with OUT_CLIP_FLAGS only
 
 
 _lib = None
@@ -215,11 +216,12 @@ class Dspi:
         return int(self.L.dspi_tile_streams(self.h))
 
     def process_host(self, pcm: np.ndarray, n_blocks: int, block_len: int, bit_depth: int = 16,
-                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False, out=None, enabled_only=False, i2s_slots=False, spdif=False):
+                     want_pairs=True, want_sub=True, want_peaks=True, tiled=False, out=None, enabled_only=False, i2s_slots=False, spdif=False, clip=False):
         """Host-memory convenience path (tests): pcm = int16 [streams][frames][2] or uint8 [streams][frames*6].
         Returns (pairs [S][P][F][2], sub [S][F], peaks [S][blocks][C]); with tiled=True the sample words come back in
         the DSPI_OUT_TILED layout: pairs [tiles][outputs][F][R], sub [tiles][F][R] (see untile()); with spdif=True (DSPI_OUT_SPDIF)
-        pairs are the IEC 60958 subframes, uint32 [S][P][F][4]."""
+        pairs are the IEC 60958 subframes, uint32 [S][P][F][4].  clip=True (DSPI_OUT_CLIP_FLAGS): every stream's sticky clip flags after the
+        call are left in self.last_clip, uint16 [S]."""
         S, F = self.n_streams, n_blocks * block_len
         pcm = np.ascontiguousarray(pcm)
         assert pcm.nbytes == S * F * (6 if bit_depth == 24 else 4), (pcm.shape, S, F)
@@ -234,8 +236,9 @@ class Dspi:
             pairs = (np.zeros((S, self.P, F, 4), dtype=np.uint32) if spdif else np.zeros((S, self.P, F, 2), dtype=np.int32)) if want_pairs else None
             sub = np.zeros((S, F), dtype=np.int32) if want_sub else None
         peaks = np.zeros((S, n_blocks, self.C), dtype=np.uint16) if want_peaks else None
-        out = _Out(pairs.ctypes.data if want_pairs else None, sub.ctypes.data if want_sub else None, peaks.ctypes.data if want_peaks else None)
-        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0) | (OUT_SPDIF if spdif else 0)), "process")
+        self.last_clip = np.zeros(S, dtype=np.uint16) if clip else None
+        out = _Out(pairs.ctypes.data if want_pairs else None, sub.ctypes.data if want_sub else None, peaks.ctypes.data if want_peaks else None, self.last_clip.ctypes.data if clip else None)
+        self._ck(self.L.dspi_process(self.h, pcm.ctypes.data, bit_depth, n_blocks, block_len, C.byref(out), (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0) | (OUT_SPDIF if spdif else 0) | (OUT_CLIP_FLAGS if clip else 0)), "process")
         return pairs, sub, peaks
 
     def untile(self, pairs_t: np.ndarray, sub_t: np.ndarray):
@@ -251,10 +254,11 @@ class Dspi:
         return pairs, sub
 
     def process_device(self, pcm_ptr: int, n_blocks: int, block_len: int, bit_depth: int = 16,
-                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0, tiled: bool = False, enabled_only: bool = False, i2s_slots: bool = False, spdif: bool = False):
-        """Zero-copy path: raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous, see sync()."""
-        out = _Out(pairs_ptr or None, sub_ptr or None, peaks_ptr or None)
-        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE | (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0) | (OUT_SPDIF if spdif else 0)), "process")
+                       pairs_ptr: int = 0, sub_ptr: int = 0, peaks_ptr: int = 0, tiled: bool = False, enabled_only: bool = False, i2s_slots: bool = False, spdif: bool = False,
+                       clip_ptr: int = 0):
+        """Zero-copy path: raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous, see sync().  clip_ptr: uint16 [S] (DSPI_OUT_CLIP_FLAGS)."""
+        out = _Out(pairs_ptr or None, sub_ptr or None, peaks_ptr or None, clip_ptr or None)
+        self._ck(self.L.dspi_process(self.h, pcm_ptr, bit_depth, n_blocks, block_len, C.byref(out), MEM_DEVICE | (OUT_TILED if tiled else 0) | (OUT_ENABLED_ONLY if enabled_only else 0) | (OUT_I2S_SLOTS if i2s_slots else 0) | (OUT_SPDIF if spdif else 0) | (OUT_CLIP_FLAGS if clip_ptr else 0)), "process")
 
     def pdm_host(self, sub: np.ndarray, tiled: bool = False) -> np.ndarray:
         """PDM sub output (dspi_pdm_modulate) on host arrays: sub int32 [streams][frames] -> uint32 [streams][frames][8];

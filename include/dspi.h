@@ -41,10 +41,11 @@
 extern "C" {
 #endif
 
-#define DSPI_ABI_VERSION 6   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
+#define DSPI_ABI_VERSION 7   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
                               * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1,
                               * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, DSPI_OUT_I2S_SLOTS, DSPI_BOOT_POPULATED_FLASH, dspi_debug_launch_plan counts[5];
-                              * 6: DSPI_OUT_SPDIF, dspi_spdif_block_pos (additions only) */
+                              * 6: DSPI_OUT_SPDIF, dspi_spdif_block_pos; 7: dspi_out.clip_flags behind DSPI_OUT_CLIP_FLAGS, DSPI_OUT_SPDIF on every
+                              * context, (additions only: a v6 caller's three-member dspi_out is never read past `peaks`) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -59,11 +60,16 @@ extern "C" {
 #define DSPI_FLOAT_CONTRACT_FMA 0x100
 #define DSPI_FLAVOR_RP2350_F32_FMA (DSPI_FLAVOR_RP2350_F32 | DSPI_FLOAT_CONTRACT_FMA)
 /* OR into the flavour of dspi_create: what the power-on models.  By default every stream is a device that boots for the FIRST time on an
- * erased flash: preset_boot_load writes the fresh preset directory (flash_storage.c:1086-1090), and every flash sector write arms the
+ * erased flash: preset_boot_load writes the fresh preset directory (flash_storage.c:1097-1100), and every flash sector write arms the
  * preset mute for flash_mute_hold_samples() = max(10 ms, 512) samples (:272-276, :347-348) — so a new context starts with 512 muted
  * samples and the fade-in (5 to 12 ms of silence / ramp at the start of the first packets).  With DSPI_BOOT_POPULATED_FLASH the streams
  * are devices whose flash already holds a directory: nothing is written at boot, audio starts unmuted; load the preset such a device
- * would have booted with dspi_load_flash_dump / dspi_load_preset_slot. */
+ * would have booted with dspi_load_flash_dump / dspi_load_preset_slot.  LIMITATION: both apply the preset the way REQ_PRESET_LOAD does
+ * on a RUNNING device (preset_load, flash_storage.c:794-849: the max(10 ms, 512)-sample mute is armed, the delay lines are zeroed),
+ * whereas the firmware's boot path (preset_boot_load -> apply_slot_to_live, :1047-1082) writes no flash and arms no mute: a device
+ * that boots a NON-default preset from a populated flash is therefore modelled from the end of that mute on, not from frame 0
+ * (tests/test_gpu_parity.py::test_flash_dump_boots_device_context compares with the firmware build after the mutes have run out;
+ * the factory-default preset, which needs no load, is exact from frame 0: ::test_boot_from_populated_flash_has_no_first_boot_mute). */
 #define DSPI_BOOT_POPULATED_FLASH 0x200
 
 #define DSPI_ALL_STREAMS (-1)
@@ -92,16 +98,19 @@ extern "C" {
                                     * subframes of spdif_update_subframe (pico_audio_spdif_multi, sample_encoding.h:27-47; dspi_spdif_encode below) —
                                     *   pairs  uint32 [stream][pair][F][4]   {left lo, left hi, right lo, right hi}: TWICE the bytes of the word layout —
                                     * the words dspi_process + dspi_spdif_encode give, without the second pass (8 bytes in, 16 out per frame and pair).
-                                    * The position in the 192-frame channel-status block runs on from call to call (dspi_spdif_block_pos).  Served by
-                                    * the float chain's latency layout (small contexts: up to 2 048 streams on a shared preset, 1 024 with presets of their own; its output waves hold both
-                                    * sides of a pair of a frame in one lane and have time to spare); launches that run on other kernels return
-                                    * DSPI_E_UNSUPPORTED — there the encoder would cost the chain 60 % more instructions and the
-                                    * two-call sequence is the fast path.  Not with DSPI_OUT_TILED or DSPI_OUT_I2S_SLOTS. */
+                                    * The position in the 192-frame channel-status block runs on from call to call (dspi_spdif_block_pos); the
+                                    * sample-rate byte of the channel status is each stream's own rate (audio_spdif.c:250-256).  On EVERY context:
+                                    * where the float chain's latency layout serves the launch (small contexts) its output waves encode the
+                                    * subframes themselves; on every other launch the library runs the chain into a scratch buffer of pair words,
+                                    * row chunk by row chunk, and the subframe encoder from there (on the packed kernel the fused encoder would
+                                    * cost the chain 60 % more instructions).  Not with DSPI_OUT_TILED or DSPI_OUT_I2S_SLOTS. */
 #define DSPI_OUT_ENABLED_ONLY 0x4u /* the caller does not read the sample words of SILENT outputs — an S/PDIF pair whose two outputs are
                                     * disabled (the firmware zero-fills it, usb_audio.c:930-933), the sub while it is disabled or Core 1
                                     * runs the EQ worker — so the library may leave those parts of pairs / sub unwritten instead of storing
                                     * zeros (36 of the 40 bytes per frame for a preset with one live pair).  Peaks, status and every live
-                                    * output are unaffected.  Honoured by the float chain's latency layout; the other kernels write the zeros. */
+                                    * output are unaffected.  Honoured by the float chain's latency layout; the other kernels write the zeros
+                                    * (host buffers: the silent parts come back as zeros either way). */
+#define DSPI_OUT_CLIP_FLAGS 0x20u  /* the dspi_out passed has the ABI-7 member clip_flags (below) and the library may write through it */
 
 typedef struct dspi_ctx dspi_ctx;
 
@@ -109,6 +118,7 @@ typedef struct dspi_ctx dspi_ctx;
  *   pairs      int32 [stream][pair][F][2]   pair p = outputs 2p,2p+1; 24-bit sample per word
  *   sub        int32 [stream][F]            PDM sub channel, Q28 (zeros when the firmware would push nothing)
  *   peaks      uint16 [stream][block][C]    per-packet peak meters (global_status.peaks, config.h:455-460)
+ *   clip_flags uint16 [stream]              sticky clip bits (with DSPI_OUT_CLIP_FLAGS only, see the member)
  * where C = 11 / 7 channels and pair count = 4 / 2.
  *
  * With DSPI_OUT_TILED the sample words are stream-minor instead ("tiles" of R = dspi_tile_streams() consecutive
@@ -123,6 +133,10 @@ typedef struct dspi_out {
     int32_t *pairs;
     int32_t *sub;
     uint16_t *peaks;
+    uint16_t *clip_flags;  /* ABI 7, read ONLY when flags carry DSPI_OUT_CLIP_FLAGS: uint16 [stream], every stream's sticky clip bits after the
+                            * call's last packet — global_status.clip_flags as REQ_GET_STATUS reports them (usb_audio.c:2427-2443: bit c =
+                            * channel c's peak exceeded full scale since the last REQ_CLEAR_CLIPS) — one pass instead of a dspi_get_status
+                            * per stream.  Not cleared by reading. */
 } dspi_out;
 
 /* ---- lifecycle ---------------------------------------------------------------------- */

@@ -1095,7 +1095,7 @@ orc_ctx *orc_new(void) {
     recalculate_all_filters(c, 48000.0f);
     set_volume_(c, 0);
     /* core0_init (main.c:645-696): preset_boot_load on blank flash = factory defaults, and the fresh directory is written
-     * (flash_storage.c:1086-1090): flash_write_sector re-arms the preset mute for flash_mute_hold_samples() = max(10 ms, 512)
+     * (flash_storage.c:1097-1100): flash_write_sector re-arms the preset mute for flash_mute_hold_samples() = max(10 ms, 512)
      * samples at the power-on 44.1 kHz (:262-266, :349-350) — found by running the firmware build (tests/test_oracle_vs_fw.py) */
     prepare_pipeline_reset(c, 512);
     recalculate_all_filters(c, 48000.0f); update_delay_samples(c, 48000.0f);

@@ -53,7 +53,8 @@ def compare(flavor, fs, B, blocks, S, blob, vol=-20 * 256, depth=16, calls=2, ch
     bpf = 2 if depth == 16 else 6
     for c in range(calls):        # several launches: state must carry across dspi_process calls
         sl = data[:, c * per * B:(c + 1) * per * B] if depth == 16 else data[:, c * per * B * 6:(c + 1) * per * B * 6]
-        outs.append(d.process_host(np.ascontiguousarray(sl), per, B, depth))
+        outs.append(d.process_host(np.ascontiguousarray(sl), per, B, depth, clip=True))
+    clip_flags = d.last_clip          # dspi_out.clip_flags (DSPI_OUT_CLIP_FLAGS): every stream's sticky bits after the last call
     pairs = np.concatenate([o[0] for o in outs], axis=2); sub = np.concatenate([o[1] for o in outs], axis=1); peaks = np.concatenate([o[2] for o in outs], axis=1)
     for s in (check_streams if check_streams is not None else range(S)):
         (rp, rs, rk, rclip), status = oracle_run(flavor, fs, vol, blob, data[s], per * calls, B, depth, setup)
@@ -61,6 +62,7 @@ def compare(flavor, fs, B, blocks, S, blob, vol=-20 * 256, depth=16, calls=2, ch
         assert np.array_equal(rs, sub[s]), f"sub differs, stream {s}"
         assert np.array_equal(rk, peaks[s]), f"peaks differ, stream {s}"
         assert status == d.status(s), f"status differs, stream {s}"
+        assert int(clip_flags[s]) == int.from_bytes(status[-2:], "little") == rclip, f"clip flags differ, stream {s}"
     d.close()
 
 
@@ -754,6 +756,75 @@ def test_full_size_stream_major_groups_agree(flavor, fs, B, blocks):
     d.close()
 
 
+@pytest.mark.parametrize("flavor,S,bands,tiled", [(W.F32_FMA, 65536, False, False), (W.F32_FMA, 65536, False, True), (W.F32_FMA, 65536, True, False), (W.F32_FMA, 65536, True, True),
+                                                  (1, 65536, True, True), (0, 16384, True, False), (0, 16384, True, True)],
+                         ids=("fma-values-stream", "fma-values-tiled", "fma-bands-stream", "fma-bands-tiled", "canonical-bands-tiled", "q28-16384-stream", "q28-16384-tiled"))
+def test_full_size_per_stream_presets(flavor, S, bands, tiled, monkeypatch):
+    """SURVEY 8f-1 at the size bench.py --config perstream / perstream_eq quotes: EVERY stream its own parameter image (65 536 float /
+    16 384 Q28 distinct objects, dsp_compute_coefficients per device: dsp_pipeline.c:61-175), the numbers taken from a table that repeats
+    every row (preamp per stream; `bands`: a master EQ band's gain per stream too, so the band coefficients differ and the float rows take
+    chain_kernel_pk<..., PV, PVB> instead of <..., PV>; Q28: the per-lane-parameter mode of every row).  Every row gets the same input, so
+    every row must produce row 0's words, sub words and peaks over three launches — value tiles, per-row launch lists and the image table
+    at 512 / 256 workgroups — and row 0's sampled streams are checked against their own oracles."""
+    import torch
+    fl = int(flavor)
+    if not fl: monkeypatch.delenv("DSPI_Q28_WAVES", raising=False)
+    fs, B, blocks, calls = (96000, 96, 6, 3) if fl else (48000, 48, 10, 3)
+    n_out, n_ch, n_pairs = (9, 11, 4) if fl else (5, 7, 2)
+    blob = WL.full_chain_blob(fl)
+    d = Dspi(flavor, S, device=0)
+    d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(blob) == 0
+    R = d.tile_streams()
+
+    def requests(col):
+        reqs = [(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -9.0 + 0.05 * col))]
+        if bands:
+            p = blob["eq"][0][1]
+            reqs.append((W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", 0, 1, int(p["type"]), 0, float(p["freq"]), float(p["q"]), 1.0 + 0.03 * col)))
+        return reqs
+    table = [requests(col) for col in range(R)]
+    for s in range(S):
+        for req, wv, pl in table[s % R]: assert d.vendor_set(req, wv, pl, stream=s) == 0
+    assert d.image_count() == S
+    base = WL.synth_pcm16(R, B * blocks * calls, fs)
+    dev = torch.device("cuda", 0)
+    groups, frames = S // R, B * blocks
+    if tiled: pairs = torch.empty((groups, n_out - 1, frames, R), dtype=torch.int32, device=dev); sub = torch.empty((groups, frames, R), dtype=torch.int32, device=dev)
+    else: pairs = torch.empty((S, n_pairs, frames, 2), dtype=torch.int32, device=dev); sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
+    peaks = torch.empty((S, blocks, n_ch), dtype=torch.int16, device=dev)
+    for c in range(calls):
+        part = torch.from_numpy(np.ascontiguousarray(base[:, c * frames:(c + 1) * frames])).to(dev)
+        pcm = part.repeat(groups, 1, 1).contiguous()
+        pairs.fill_(0x55555555); sub.fill_(0x55555555)
+        torch.cuda.synchronize()
+        d.process_device(pcm.data_ptr(), blocks, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled); d.sync()
+        pv = pairs if tiled else pairs.view(groups, R, n_pairs, frames, 2)
+        sv = sub if tiled else sub.view(groups, R, frames)
+        kv = peaks.view(groups, R, blocks, n_ch)
+        assert bool((pv == pv[0:1]).all()), f"launch {c}: a row's pair words differ from row 0"
+        assert bool((sv == sv[0:1]).all()), f"launch {c}: a row's sub words differ from row 0"
+        assert bool((kv == kv[0:1]).all()), f"launch {c}: a row's peaks differ from row 0"
+    plan = d.launch_plan()
+    if fl: assert plan["packed_per_lane_values_and_bands" if bands else "packed_per_lane_values"] == groups and plan["packed_shared"] == plan["one_stream_per_lane_images"] == plan["latency_layout"] == 0, plan
+    else: assert plan["q28_shared"] == 0 and plan["one_stream_per_lane_images"] == groups, plan
+    if tiled:
+        p0 = pairs[0].cpu().numpy(); s0 = sub[0].cpu().numpy()
+    else:
+        p0, s0 = pairs[:R].cpu().numpy(), sub[:R].cpu().numpy()
+    k0 = peaks[:R].cpu().numpy().view(np.uint16)
+    for s in (0, 1, R // 2 - 1, R // 2, R - 1):
+        o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-20 * 256); assert o.load_bulk(blob) == 0
+        for req, wv, pl in table[s]: assert o.vendor_set(req, wv, pl) == 0
+        rp, rs, rk, _ = o.process(base[s], blocks * calls, B, 16)
+        last = rp[:, (calls - 1) * frames:, :]
+        got = np.stack([np.stack([p0[2 * p, :, s], p0[2 * p + 1, :, s]], axis=-1) for p in range(n_pairs)]) if tiled else p0[s]
+        assert np.array_equal(last, got), (s, np.argwhere(last != got)[:3].tolist())
+        assert np.array_equal(rs[(calls - 1) * frames:], s0[:, s] if tiled else s0[s]), s
+        assert np.array_equal(rk[(calls - 1) * blocks:], k0[s]), s
+        for far in (s, s + R * (groups // 2), s + R * (groups - 1)): assert o.status() == d.status(far), far
+    d.close()
+
+
 @pytest.mark.auto_layout
 @pytest.mark.parametrize("two_b", (False, True), ids=("config2", "config2b"))
 def test_full_size_config2_latency_layout(two_b):
@@ -891,17 +962,88 @@ def test_spdif_subframes_fused_into_the_chain(shape, fs, B, monkeypatch):
         assert fused.spdif_block_pos() == pos
     assert int(np.abs(p0[0, 0, -B:]).max()) > 0
     plain.close(); fused.close()
-    monkeypatch.setenv("DSPI_F32_LAYOUT", "packed")
-    d = Dspi(W.F32_FMA, S, device=0); d.set_rate(fs); assert d.load_bulk(blob) == 0
-    with pytest.raises(Exception): d.process_host(np.ascontiguousarray(pcm[:, :B * blocks]), blocks, B, spdif=True)
-    d.close()
+
+
+@pytest.mark.auto_layout
+@pytest.mark.parametrize("flavor,S,B", [(W.F32_FMA, 70, 48), (W.F32_FMA, 4096, 45), (W.F32_FMA, 65536, 48), (0, 150, 48), (0, 16384, 44)],
+                         ids=("f32-70-packed", "f32-4096", "f32-65536", "q28-150", "q28-16384"))
+def test_spdif_flag_on_every_context(flavor, S, B, monkeypatch):
+    """DSPI_OUT_SPDIF is a property of the output, not of the stream count: on launches the latency layout does not serve, dspi_process
+    runs the chain into a scratch buffer row chunk by row chunk and the subframe encoder from there (sample_encoding.h:27-47) — the words
+    of the two-call sequence, the block position carried across calls, any flavour, any size, device buffers; two streams get a preset of
+    their own (mixed kernels in one launch).  Sampled streams against the reference-pinned encoder of the oracle."""
+    import torch
+    fl = int(flavor)
+    if S == 70: monkeypatch.setenv("DSPI_F32_LAYOUT", "packed")
+    fs = 44100 if B in (44, 45) else 48000
+    blocks, calls = 6, 2
+    P = 4 if fl else 2
+    dev = torch.device("cuda", 0)
+    plain, fused = Dspi(flavor, S, device=0), Dspi(flavor, S, device=0)
+    for d in (plain, fused):
+        d.set_rate(fs); d.set_volume(-6 * 256); assert d.load_bulk(WL.full_chain_blob(fl)) == 0
+        for s_ in (3, S - 2): d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -9.5), stream=s_)
+    assert fused.spdif_block_pos(100) == 100
+    pos = 100
+    frames = B * blocks
+    base = WL.synth_pcm16(min(S, 256), frames * calls, fs)
+    reps = (S + base.shape[0] - 1) // base.shape[0]
+    for c in range(calls):
+        part = torch.from_numpy(np.ascontiguousarray(base[:, c * frames:(c + 1) * frames])).to(dev)
+        pcm = part.repeat(reps, 1, 1)[:S].contiguous()
+        words = torch.empty((S, P, frames, 2), dtype=torch.int32, device=dev); want = torch.empty((S, P, frames, 4), dtype=torch.int32, device=dev)
+        got = torch.full((S, P, frames, 4), 0x55555555, dtype=torch.int32, device=dev)
+        sub0 = torch.empty((S, frames), dtype=torch.int32, device=dev); sub1 = torch.empty((S, frames), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        plain.process_device(pcm.data_ptr(), blocks, B, 16, words.data_ptr(), sub0.data_ptr(), 0)
+        nxt = plain.spdif_device(words.data_ptr(), frames, pos, want.data_ptr()); plain.sync()
+        fused.process_device(pcm.data_ptr(), blocks, B, 16, got.data_ptr(), sub1.data_ptr(), 0, spdif=True); fused.sync()
+        assert fused.launch_plan()["latency_layout"] == 0 or S == 4096      # (4 096 streams on a shared preset: the size rule may take the latency layout for most lanes)
+        assert torch.equal(got, want), (c, torch.nonzero(got != want)[:3].tolist())
+        assert torch.equal(sub0, sub1)
+        for s_ in (0, 3, S // 2, S - 1):
+            w_ = words[s_].cpu().numpy(); g_ = got[s_].cpu().numpy().view(np.uint32)
+            for p_ in range(P):
+                ref, n2 = orclib.spdif_encode(w_[p_], pos, fs)
+                assert n2 == nxt and np.array_equal(ref, g_[p_]), (c, s_, p_)
+        pos = nxt
+        assert fused.spdif_block_pos() == pos
+        del words, want, got, sub0, sub1, pcm
+    plain.close(); fused.close()
+
+
+@pytest.mark.both_layouts
+def test_spdif_channel_status_follows_each_streams_rate():
+    """the sample-rate byte of the IEC 60958 channel status (audio_spdif.c:250-256) belongs to the device.  A context whose
+    streams run at three different rates: DSPI_OUT_SPDIF (fused on the latency layout, two-pass elsewhere) and dspi_spdif_encode both
+    give every stream the status bits of ITS rate — checked against the reference-pinned encoder of the oracle, over two 192-frame blocks."""
+    B, blocks, S = 48, 9, 6
+    rates = {0: 48000, 1: 44100, 2: 96000, 3: 48000, 4: 96000, 5: 44100}
+    d, e = Dspi(W.F32_FMA, S, device=0), Dspi(W.F32_FMA, S, device=0)
+    for x in (d, e):
+        x.set_volume(-6 * 256); assert x.load_bulk(WL.full_chain_blob(1)) == 0
+        for s_, r in rates.items(): assert x.set_rate(r, stream=s_) == 0
+    pcm = WL.synth_pcm16(S, B * blocks, 48000)
+    p0, _, _ = d.process_host(pcm, blocks, B)
+    sf, nxt = d.spdif_host(p0, 7)
+    e.spdif_block_pos(7)
+    p1, _, _ = e.process_host(pcm, blocks, B, spdif=True)
+    assert (e.launch_plan()["latency_layout"] > 0) == on_latency_layout()
+    assert e.spdif_block_pos() == nxt
+    for s_, r in rates.items():
+        for p_ in range(4):
+            ref, n2 = orclib.spdif_encode(p0[s_, p_], 7, r)
+            assert n2 == nxt and np.array_equal(ref, sf[s_, p_]), ("dspi_spdif_encode", s_, p_)
+            assert np.array_equal(ref, p1[s_, p_]), ("DSPI_OUT_SPDIF", s_, p_)
+    assert not np.array_equal(sf[0, 0, :40], orclib.spdif_encode(p0[0, 0], 7, 96000)[0][:40])      # (the rate does show in the first 40 frames of a block)
+    d.close(); e.close()
 
 
 @pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
 def test_boot_from_populated_flash_has_no_first_boot_mute(flavor):
     """DSPI_BOOT_POPULATED_FLASH: a context of devices that do NOT boot for the first time starts unmuted — the default context arms the
-    512-sample preset mute the firmware's first boot arms by writing its directory (flash_storage.c:1086-1090, :347-348).  Checked
+    512-sample preset mute the firmware's first boot arms by writing its directory (flash_storage.c:1097-1100, :347-348).  Checked
     against the reference's own boot path: the firmware build booted from a flash that holds a directory and the factory-default
     preset in slot 0 (no write, no mute) plays, from the first frame, what the flagged context plays."""
     fma = bool(getattr(flavor, "fma", False))
