@@ -400,7 +400,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         first, last = rank * total, (rank + 1) * total
     S = last - first
     frames = NB * B
-    _, N, _, P, _ = W.dims(flavor)
+    _, N, P, _, _ = W.dims(flavor)          # channels, outputs, S/PDIF pairs
     pcm_cache = {}
 
     def per_stream_requests(s):
