@@ -1007,8 +1007,8 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.skip_silent = (flags & DSPI_OUT_ENABLED_ONLY) ? 1u : 0u;
     a.i2s_slots = (flags & DSPI_OUT_I2S_SLOTS) ? 1u : 0u;
     if (spdif) { a.spdif = spdif_two_pass ? 0u : 1u; a.spdif_pos = c->spdif_pos; }
-    if (c->flavor && !tiled && (out->pairs || out->sub)) {      // stream-major words of the packed kernel go through its exchange area
-        const size_t xb = (size_t)c->n_wg * 2 * kMaxOut * kChunk * c->sm.row * 4;
+    if (c->flavor && !tiled) {      // stream-major layout, packed kernel: the mini lines of the outputs whose rows do not reach the emit wave through their delay line (dspi_chain_pk.inc)
+        const size_t xb = (size_t)c->n_wg * 3 * kMaxOut * kChunk * c->sm.row * 4;
         if ((rc = ensure(c, c->d_xwords, c->d_xwords_cap, xb))) return rc;
         a.xwords = c->d_xwords;
     }

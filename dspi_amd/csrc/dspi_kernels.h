@@ -22,7 +22,7 @@ struct KArgs {
     uint32_t n_streams, n_blocks, block_len, bit_depth;
     const uint32_t *stream_image;   // [n_streams] image index of every stream (float one-stream kernel: per-lane parameters)
     uint32_t tiled_out;      // DSPI_OUT_TILED: pairs = [tile][output][frames][row], sub = [tile][frames][row] (row = StateMap::row)
-    uint32_t *xwords;        // packed float kernel, stream-major output: exchange area [n_wg][2][kMaxOut][kChunk][128] words (or null: scattered stores)
+    uint32_t *xwords;        // packed float kernel, stream-major output: mini lines [n_wg][3][kMaxOut][kChunk][128] words — the rows of outputs that do not reach their pair's waves through the delay line (dspi_chain_pk.inc output_item_pk)
     const float *vals;       // packed float kernel, per-lane values: value tiles [n_wg][kPvTileFloats] (dspi_image.h) or null
     uint32_t skip_silent;    // DSPI_OUT_ENABLED_ONLY: sample words of silent outputs (a disabled S/PDIF pair, the sub while it is off) need not be stored
     uint32_t i2s_slots;      // DSPI_OUT_I2S_SLOTS: pairs whose slot is an I2S slot (DevImage::i2s_pairs) carry left-justified I2S words (word << 8)
