@@ -85,6 +85,8 @@ struct dspi_ctx {
     int32_t *d_sub = nullptr; size_t d_sub_cap = 0;
     uint16_t *d_peaks = nullptr; size_t d_peaks_cap = 0;
     uint16_t *d_clip = nullptr; size_t d_clip_cap = 0;          // DSPI_OUT_CLIP_FLAGS on host buffers
+    // small calls on host buffers (one packet per call, the firmware's own rhythm): a pinned host area the kernels read and write directly
+    char *h_direct = nullptr; char *d_direct = nullptr; size_t direct_cap = 0;
     int32_t *d_spdif_words = nullptr; size_t d_spdif_words_cap = 0;      // DSPI_OUT_SPDIF on launches the latency layout does not serve: the chain's pair words of one row chunk
     // PDM sub output (dspi_pdm.hip): modulator state per stream, allocated on first use; staging for host buffers
     uint32_t *d_pdm = nullptr;
@@ -688,6 +690,7 @@ void dspi_destroy(dspi_ctx *c) {
         for (void *p : {(void *)c->d_state, (void *)c->d_dlines, (void *)c->d_ring, (void *)c->d_xwords, (void *)c->d_vals, (void *)c->d_pv_rows, (void *)c->d_images, (void *)c->d_items, (void *)c->d_litems, (void *)c->d_stream_image, (void *)c->d_pdm, (void *)c->d_pdm_in, (void *)c->d_pdm_out, (void *)c->d_spdif_in, (void *)c->d_spdif_out, c->d_in,
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks, (void *)c->d_clip, (void *)c->d_spdif_words})
             if (p) (void)hipFree(p);
+        if (c->h_direct) (void)hipHostFree(c->h_direct);
         for (hipEvent_t e : c->pipe_events) (void)hipEventDestroy(e);
         if (c->hs_in) (void)hipStreamDestroy(c->hs_in);
         if (c->hs_out) (void)hipStreamDestroy(c->hs_out);
@@ -1012,8 +1015,36 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         if ((rc = ensure(c, c->d_xwords, c->d_xwords_cap, xb))) return rc;
         a.xwords = c->d_xwords;
     }
+    // ---- small calls on host buffers: the drop-in as the firmware's main loop makes it, ONE packet per call (usb_audio_drain_ring,
+    // usb_audio.c:1326-1332).  Staged copies would cost four DMA round trips (~100 us) for a few KB; instead the kernels read the packet
+    // from, and write their words to, a pinned host area directly (fine-grained, GPU-visible: hipHostMalloc), so the call is two memcpys on
+    // the CPU, the launches, and a spin on the stream: its latency is the kernel's. ----
+    constexpr size_t kDirectBytes = 2u << 20;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t off_pairs = up(in_b), off_sub = off_pairs + up(out->pairs ? pairs_b : 0), off_peaks = off_sub + up(out->sub ? sub_b : 0),
+                 off_clip = off_peaks + up(out->peaks ? peaks_b : 0), direct_b = off_clip + up(clip_out ? (size_t)c->n_streams * 2 : 0);
+    const bool no_direct = getenv("DSPI_NO_DIRECT") != nullptr;      // development / tests: the staged path for small calls too
+    const bool direct = !dev && direct_b <= kDirectBytes && !no_direct;
+    if (direct && direct_b > c->direct_cap) {
+        if (c->h_direct) { HIPCK(c, hipStreamSynchronize(c->hs)); (void)hipHostFree(c->h_direct); c->h_direct = nullptr; c->direct_cap = 0; }
+        const size_t want = std::max<size_t>(direct_b, 64u << 10);
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, want, hipHostMallocDefault) != hipSuccess) return fail(c, DSPI_E_NOMEM, "hipHostMalloc failed (direct host area)");
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipHostFree(hp); return fail(c, DSPI_E_HIP, "hipHostGetDevicePointer failed"); }
+        c->h_direct = (char *)hp; c->d_direct = (char *)dp; c->direct_cap = want;
+    }
     if (dev) {
         a.pcm = pcm_in; a.pairs = out->pairs; a.sub = out->sub; a.peaks = out->peaks;
+    } else if (direct) {
+        memcpy(c->h_direct, pcm_in, in_b);
+        a.pcm = c->d_direct;
+        if (out->pairs) a.pairs = reinterpret_cast<int32_t *>(c->d_direct + off_pairs);
+        if (out->sub) a.sub = reinterpret_cast<int32_t *>(c->d_direct + off_sub);
+        if (out->peaks) a.peaks = reinterpret_cast<uint16_t *>(c->d_direct + off_peaks);
+        if (flags & DSPI_OUT_ENABLED_ONLY) {      // (silent parts stay unwritten by the kernels: the caller finds zeros, the firmware's own fill)
+            if (out->pairs) memset(c->h_direct + off_pairs, 0, pairs_b);
+            if (out->sub) memset(c->h_direct + off_sub, 0, sub_b);
+        }
     } else {
         if ((rc = ensure(c, c->d_in, c->d_in_cap, in_b))) return rc;
         a.pcm = c->d_in;
@@ -1089,6 +1120,20 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         if ((rc = launch_rows(0, c->n_wg))) return rc;
         if (clip_out && (rc = gather_clip(clip_out))) return rc;
         if (spdif) c->spdif_pos = (uint32_t)((c->spdif_pos + frames) % 192u);      // only once everything is enqueued: a failed call leaves the block position alone
+        return DSPI_OK;
+    }
+    if (direct) {
+        if ((rc = launch_rows(0, c->n_wg))) return rc;
+        if (clip_out && (rc = gather_clip(reinterpret_cast<uint16_t *>(c->d_direct + off_clip)))) return rc;
+        // the launches take tens of microseconds: polling the stream answers within a microsecond of their end, a blocking wait adds a wake-up
+        hipError_t q;
+        while ((q = hipStreamQuery(c->hs)) == hipErrorNotReady) {}
+        if (q != hipSuccess) return fail(c, DSPI_E_HIP, std::string("stream: ") + hipGetErrorString(q));
+        if (out->pairs) memcpy(out->pairs, c->h_direct + off_pairs, pairs_b);
+        if (out->sub) memcpy(out->sub, c->h_direct + off_sub, sub_b);
+        if (out->peaks) memcpy(out->peaks, c->h_direct + off_peaks, peaks_b);
+        if (clip_out) memcpy(clip_out, c->h_direct + off_clip, (size_t)c->n_streams * 2);
+        if (spdif) c->spdif_pos = (uint32_t)((c->spdif_pos + frames) % 192u);
         return DSPI_OK;
     }
 

@@ -863,6 +863,41 @@ def test_full_size_config2_latency_layout(two_b):
     d.close()
 
 
+@pytest.mark.auto_layout
+@pytest.mark.parametrize("flavor,S", [(W.F32_FMA, 1), (W.F32_FMA, 70), (1, 300), (0, 1), (0, 100)])
+def test_small_host_calls_take_the_direct_path(flavor, S, monkeypatch):
+    """The drop-in call as the firmware's main loop makes it (usb_audio.c:1326-1332): ONE packet per dspi_process on host buffers.  Such
+    calls (<= 2 MB of buffers) skip the staged copies — the kernels read the packet from, and write to, a pinned host area — and must
+    give what the staged path gives (DSPI_NO_DIRECT=1 on a second context): every word, peak, clip flag over 40 calls of one packet,
+    with DSPI_OUT_ENABLED_ONLY, DSPI_OUT_I2S_SLOTS and DSPI_OUT_SPDIF in turn; stream 0 and S-1 against the oracle."""
+    fl = int(flavor)
+    fs, B = (96000, 96) if fl else (48000, 48)
+    calls = 40
+    blob = WL.full_chain_blob(fl)
+    blob["outputs"][2]["enabled"] = 0; blob["outputs"][3]["enabled"] = 0          # a silent pair (ENABLED_ONLY)
+    d, e = Dspi(flavor, S, device=0), Dspi(flavor, S, device=0)
+    for x in (d, e): x.set_rate(fs); x.set_volume(-6 * 256); assert x.load_bulk(blob) == 0
+    pcm = WL.synth_pcm16(S, B * calls, fs, first_stream=19)          # (stream class 19: the full-scale square sets clip flags)
+    got = []
+    for c in range(calls):
+        part = np.ascontiguousarray(pcm[:, c * B:(c + 1) * B])
+        kw = dict(enabled_only=(c % 4 == 1), i2s_slots=(c % 4 == 2), spdif=(c % 4 == 3), clip=True)
+        monkeypatch.delenv("DSPI_NO_DIRECT", raising=False)
+        p0, s0, k0 = d.process_host(part, 1, B, **kw); c0 = d.last_clip.copy()
+        monkeypatch.setenv("DSPI_NO_DIRECT", "1")
+        p1, s1, k1 = e.process_host(part, 1, B, **kw); c1 = e.last_clip.copy()
+        assert np.array_equal(p0, p1) and np.array_equal(s0, s1) and np.array_equal(k0, k1) and np.array_equal(c0, c1), c
+        if c % 4 == 0: got.append((c, p0, s0, k0))
+    monkeypatch.delenv("DSPI_NO_DIRECT", raising=False)
+    for s_ in sorted({0, S - 1}):
+        o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-6 * 256); assert o.load_bulk(blob) == 0
+        rp, rs, rk, _ = o.process(pcm[s_], calls, B)
+        for c, p0, s0, k0 in got:
+            assert np.array_equal(rp[:, c * B:(c + 1) * B], p0[s_]) and np.array_equal(rs[c * B:(c + 1) * B], s0[s_]) and np.array_equal(rk[c], k0[s_, 0]), (s_, c)
+        assert o.status() == d.status(s_)
+    d.close(); e.close()
+
+
 @pytest.mark.parametrize("flavor,tiled", [(W.F32_FMA, False), (1, True), (0, False), (0, True)])
 def test_host_buffer_pipeline_chunks(flavor, tiled):
     """dspi_process on HOST buffers large enough to take the chunked pipeline (rows cut into chunks, H2D / kernels / D2H of consecutive

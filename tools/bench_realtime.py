@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""tools/bench_realtime.py — the drop-in call as INTEGRATION.md section 3 writes it, timed and checked (run via gpurun).
+
+The reference's main loop hands ONE packet to process_audio_packet per USB frame (usb_audio_drain_ring, firmware/DSPi/usb_audio.c:1326-1332;
+its budget is 500-800 us of the 1 000 us packet, Documentation/Features/buffer_statistics_spec.md:153).  This drives the C host
+(dspi_amd/csrc/dspi_host -rt: plain C over include/dspi.h) the same way: one 96-frame packet per dspi_process(), HOST buffers, 10 000 calls
+back to back, for 1 / 16 / 128 streams and both flavours; prints p50 / p99 / max latency per call and the sustained rate against real time;
+and checks every word of every call of streams 0 and S-1 against the oracle (state carried from call to call).
+
+    python tools/bench_realtime.py [--calls 10000] [--streams 1,16,128] [--out profiles/r04_realtime.json]
+"""
+import argparse, json, os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from dspi_amd import wire as W, workloads as WL
+from orclib import Oracle
+
+HOST = os.path.join(ROOT, "dspi_amd", "csrc", "dspi_host")
+
+
+def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None):
+    fl = int(flavor)
+    blob = WL.full_chain_blob(fl)
+    pcm = WL.synth_pcm16(1, B * packets, fs, first_stream=3)[0]           # the file every stream plays (stream s is s packets behind)
+    ref = Oracle(fl); assert ref.load_bulk(blob) == 0
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "bulk.bin"), "wb").write(ref.collect_bulk())
+        open(os.path.join(td, "pcm.raw"), "wb").write(np.ascontiguousarray(pcm).tobytes())
+        cmd = [HOST, "-rt", "-f", flavor_name, "-s", str(S), "-r", str(fs), "-b", str(B), "-c", str(calls), "-B", os.path.join(td, "bulk.bin"),
+               "-i", os.path.join(td, "pcm.raw"), "-O", os.path.join(td, "all.raw"), "-L", os.path.join(td, "lat.f64"), "-v", "-20"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(os.environ, **(env or {})))
+        if r.returncode != 0: raise SystemExit(f"dspi_host failed: {r.stdout}\n{r.stderr}")
+        line = [l for l in r.stdout.splitlines() if l.startswith("rt:")][0]
+        m = re.search(r"p50 ([\d.]+) us\s+p99 ([\d.]+) us\s+p99.9 ([\d.]+) us\s+max ([\d.]+) us\s+\(first (\d+) calls: max ([\d.]+) us\)\s+mean ([\d.]+) us = ([\d.]+) x real time", line)
+        rec = dict(flavor=flavor_name, streams=S, fs=fs, block_len=B, calls=calls, p50_us=float(m.group(1)), p99_us=float(m.group(2)), p999_us=float(m.group(3)), max_us=float(m.group(4)),
+                   first_calls=int(m.group(5)), first_calls_max_us=float(m.group(6)), mean_us=float(m.group(7)), realtime_x=float(m.group(8)), packet_us=B / fs * 1e6)
+        lat = np.fromfile(os.path.join(td, "lat.f64"), dtype=np.float64)
+        rec["over_packet_time"] = int((lat[rec["first_calls"]:] > B / fs).sum())      # calls (steady state) that took longer than the packet they carry
+        if check:
+            P, C = (4, 11) if fl else (2, 7)
+            per = P * B * 2 + B          # int32 words per call and stream, then C uint16
+            raw = np.fromfile(os.path.join(td, "all.raw"), dtype=np.uint8)
+            n_watch = 2 if S > 1 else 1
+            rec_b = per * 4 + C * 2
+            raw = raw.reshape(calls, n_watch, rec_b)
+            for wi, s in enumerate([0, S - 1][:n_watch]):
+                o = Oracle(flavor, detmath=True); assert o.set_rate(fs) == 0; o.set_volume(-20 * 256); assert o.load_bulk(ref.collect_bulk()) == 0
+                idx = (np.arange(calls)[:, None] - (s % packets)) % packets          # the packet stream s plays at call c
+                data = pcm.reshape(packets, B, 2)[idx[:, 0]].reshape(calls * B, 2)
+                rp, rs, rk, _ = o.process(np.ascontiguousarray(data), calls, B)
+                got = raw[:, wi]
+                gp = got[:, :P * B * 8].copy().view(np.int32).reshape(calls, P, B, 2).transpose(1, 0, 2, 3).reshape(P, calls * B, 2)
+                gs = got[:, P * B * 8:per * 4].copy().view(np.int32).reshape(calls * B)
+                gk = got[:, per * 4:].copy().view(np.uint16).reshape(calls, C)
+                if not (np.array_equal(rp, gp) and np.array_equal(rs, gs) and np.array_equal(rk, gk)):
+                    raise SystemExit(f"PARITY FAILURE: {flavor_name}, {S} streams, stream {s}: first differing call {int(np.argwhere((rp != gp).any(axis=(0, 2)).reshape(calls, B).any(axis=1))[0][0]) if not np.array_equal(rp, gp) else -1}")
+            rec["parity"] = f"bit-exact vs the oracle over {calls} calls, streams {[0, S - 1][:n_watch]}"
+        print(json.dumps(rec), flush=True)
+        return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--calls", type=int, default=10000)
+    ap.add_argument("--streams", default="1,16,128")
+    ap.add_argument("--flavors", default="f32fma,q28")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--no-check", action="store_true")
+    a = ap.parse_args()
+    recs = []
+    for fname in a.flavors.split(","):
+        flavor = {"f32fma": W.F32_FMA, "f32": 1, "q28": 0}[fname]
+        fs, B = (96000, 96) if int(flavor) else (48000, 48)
+        for S in [int(x) for x in a.streams.split(",")]:
+            recs.append(run(fname, flavor, S, fs, B, a.calls, 1000, check=not a.no_check))
+    if a.out:
+        json.dump({"what": "dspi_host -rt: one packet per dspi_process(), host buffers, back to back (tools/bench_realtime.py)", "runs": recs}, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
