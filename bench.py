@@ -355,7 +355,7 @@ def main():
         out = bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_range)
     if dist and out is not None:      # (ranks other than 0 return None)
         out["dist"] = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world_size": world,
-                       "collective": "all_reduce(MAX) of the elapsed time, 8 bytes, after the timed region"}
+                       "collective": "all_reduce(SUM) of the frames + all_reduce(MAX) of the elapsed time, 8 bytes each, after the timed region (dspi_amd/shard.py)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist: dist.destroy_process_group()
@@ -382,11 +382,7 @@ def timed_steps(args, torch, dist, backend, dev, ctx, step):
     elapsed = t1 - t0
     timed_steps.window = (t0, t1)
     kernel_ms = ev.elapsed_ms(e0, e1) / args.steps
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the only collective: 8 bytes
-        elapsed = float(t.item())
-    return elapsed, kernel_ms
+    return elapsed, kernel_ms      # (this rank's; the reduction over ranks is dspi_amd/shard.py:reduce_throughput, the job's only collective)
 
 
 def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_range):
@@ -478,8 +474,9 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
                                                                     enabled_only=bool(w.get("enabled_only"))))
         if smi: smi.stop()
         plan = ctx.launch_plan()
-        n_total = total if args.scaling == "strong" else total * world
-        fps = float(n_total) * frames * args.steps / elapsed
+        # whole job: frames of all ranks / the slowest rank's time — sum and max over ranks, 2 x 8 bytes over RCCL
+        from dspi_amd.shard import reduce_throughput
+        _, elapsed, fps = reduce_throughput(dist, float(S) * frames * args.steps, elapsed, device=dev if backend == "nccl" else "cpu")
         m = dict(contract=contract if flavor == 1 else "integer", out_layout=layout, input=inp, frames_per_s=fps, value=fps * CH,
                  ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms, latency_layout=plan.get("latency_layout", 0) > 0)
         if w.get("enabled_only"): m["enabled_only"] = True      # (silent pairs and the sub are not zero-filled: fewer bytes than the firmware's own stores)

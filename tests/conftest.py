@@ -12,6 +12,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "both_layouts: run the GPU test once on the packed float kernel and once on the latency layout (DSPI_F32_LAYOUT)")
     config.addinivalue_line("markers", "auto_layout: leave the choice between the packed kernel and the latency layout to the library's size rule")
+    config.addinivalue_line("markers", "all_layouts: both_layouts plus a third run under the library's own size rule")
 
 
 @pytest.fixture(scope="session")
@@ -44,13 +45,16 @@ def _layout(request, monkeypatch):
     once on each, `auto_layout` leaves the size rule in charge, and a test that sets the variable itself (monkeypatch) wins."""
     if not request.node.get_closest_marker("gpu"):
         yield; return
-    if request.node.get_closest_marker("auto_layout"): monkeypatch.delenv("DSPI_F32_LAYOUT", raising=False)
-    else: monkeypatch.setenv("DSPI_F32_LAYOUT", "skew" if getattr(request, "param", "packed") == "latency" else "packed")
+    param = getattr(request, "param", "packed")
+    if request.node.get_closest_marker("auto_layout") or param == "auto": monkeypatch.delenv("DSPI_F32_LAYOUT", raising=False)
+    else: monkeypatch.setenv("DSPI_F32_LAYOUT", "skew" if param == "latency" else "packed")
     yield
 
 
 def pytest_generate_tests(metafunc):
-    if metafunc.definition.get_closest_marker("both_layouts") and "_layout" in metafunc.fixturenames:
+    if metafunc.definition.get_closest_marker("all_layouts") and "_layout" in metafunc.fixturenames:
+        metafunc.parametrize("_layout", ["packed", "latency", "auto"], indirect=True)      # "auto": the library's own size rule picks the kernel
+    elif metafunc.definition.get_closest_marker("both_layouts") and "_layout" in metafunc.fixturenames:
         metafunc.parametrize("_layout", ["packed", "latency"], indirect=True)
 
 

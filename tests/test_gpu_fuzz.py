@@ -62,7 +62,7 @@ def random_blob(rng, flavor, fs):
     return b
 
 
-@pytest.mark.both_layouts
+@pytest.mark.all_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 12))))      # more seeds: DSPI_FUZZ_SEEDS=200 pytest ...
 def test_random_presets(flavor, seed):
@@ -114,7 +114,7 @@ def random_request(rng, flavor, fs):
     return R["SET_MASTER_VOLUME"], 0, f(rng.choice([0.0, -128.0, rng.uniform(-70, 0)]))
 
 
-@pytest.mark.both_layouts
+@pytest.mark.all_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 6))))
 def test_random_request_sequences(flavor, seed):
@@ -170,7 +170,7 @@ def test_random_request_sequences(flavor, seed):
     d.close()
 
 
-@pytest.mark.both_layouts
+@pytest.mark.all_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 6))))
 def test_output_pointer_and_layout_combinations(flavor, seed):
