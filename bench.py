@@ -445,7 +445,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         return {"parity_checked": len(sample), "parity_streams": [first + s for s in sample], "parity_launches_replayed": launches,
                 "parity_what": "every pair word, sub word, peak of the timed context's last launch + the status bytes, bit-exact vs the CPU oracle", "parity_s": time.perf_counter() - t0}
 
-    def measure(contract, layout, inp, check=False):
+    def measure(contract, layout, inp, check=False, enabled_only=None):
         fma = (contract == "fma") and flavor == 1
         ctx = Dspi(flavor, S, device=dev.index, fma=fma)
         ctx.set_rate(FS); ctx.set_volume(w["vol"])
@@ -471,7 +471,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         if smi: smi.start()
         elapsed, kernel_ms = timed_steps(args, torch, dist, backend, dev, ctx,
                                          lambda: ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled,
-                                                                    enabled_only=bool(w.get("enabled_only"))))
+                                                                    enabled_only=bool(w.get("enabled_only")) if enabled_only is None else enabled_only))
         if smi: smi.stop()
         plan = ctx.launch_plan()
         # whole job: frames of all ranks / the slowest rank's time — sum and max over ranks, 2 x 8 bytes over RCCL
@@ -479,7 +479,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         _, elapsed, fps = reduce_throughput(dist, float(S) * frames * args.steps, elapsed, device=dev if backend == "nccl" else "cpu")
         m = dict(contract=contract if flavor == 1 else "integer", out_layout=layout, input=inp, frames_per_s=fps, value=fps * CH,
                  ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms, latency_layout=plan.get("latency_layout", 0) > 0)
-        if w.get("enabled_only"): m["enabled_only"] = True      # (silent pairs and the sub are not zero-filled: fewer bytes than the firmware's own stores)
+        m["enabled_only"] = bool(w.get("enabled_only")) if enabled_only is None else enabled_only      # True: silent pairs and the sub are not zero-filled (fewer bytes than the firmware's own stores)
         if smi: m["power"] = smi.window(*timed_steps.window) if smi.ok else None
         if check and rank == 0 and not args.no_parity:
             m["parity"] = parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, args.warmup + args.steps)
@@ -496,6 +496,8 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         for c, l, i in [(oc, args.out_layout, args.input) for oc in other_contract] + [(args.contract, other_layout, args.input)] + \
                        [(oc, other_layout, args.input) for oc in other_contract] + [(args.contract, args.out_layout, "noise" if args.input == "mix" else "mix")]:
             also.append(measure(c, l, i))
+        if w.get("enabled_only"):      # the same workload with the firmware's own zero-fill of the silent pairs and the sub (usb_audio.c:930-933): what earlier rounds' BENCH files measured
+            also.append(measure(args.contract, args.out_layout, args.input, enabled_only=False))
     if rank != 0:
         return None
 
