@@ -308,6 +308,51 @@ def test_latency_layout_mixed_with_other_kernels(flavor, monkeypatch):
     d.close()
 
 
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+@pytest.mark.parametrize("tiled", (True, False), ids=("tiled", "stream"))
+@pytest.mark.parametrize("fs,B", [(96000, 96), (44100, 45), (48000, 7)])
+def test_words_written_ahead_keep_the_lines_history(flavor, tiled, fs, B):
+    """The packed kernel writes the word of frame f + dly at frame f (tiled layout: every output; stream-major: the sub) and stores a
+    launch's last 4 096 frames to the line whatever the delay, because the reference's lines always hold the last 4 096 samples and a
+    LATER, LONGER delay reads further back (REQ_SET_OUTPUT_DELAY clears nothing: usb_audio.c:1944-1951).  Launches of very different
+    lengths (one packet ... longer than the lines), delays shorter and longer than a launch, not multiples of the packet, at the aliasing
+    maximum, growing and shrinking between launches, an output switched to delay 0 and back: every word, sub word, peak and status
+    byte against the oracle fed the same requests."""
+    S = 9
+    blob = WL.full_chain_blob(1)
+    line_ms = 4096 * 1000.0 / fs
+    delays0 = [0.0, 0.4, 1.0, 3.3, 7.1, 0.1, line_ms - 1.0, 20.0, 5.0]
+    for o in range(9): blob["outputs"][o]["delay_ms"] = delays0[o]
+    d = Dspi(flavor, S, device=0); o_ = [Oracle(flavor, detmath=True) for _ in range(S)]
+    for x in [d] + o_:
+        assert x.set_rate(fs) == 0
+        x.set_volume(-9 * 256); assert x.load_bulk(blob) == 0
+    f = lambda v: struct.pack("<f", v)
+    R = W.REQ
+    # (packets per launch, requests before it): delays grow past what the previous launches' own delays needed, shrink, go to 0 and come back
+    plan = [(1, []), (50, []), (3, [(2, 9.0), (5, 30.0)]), (1, [(2, 0.0)]), (4600 // B + 1, [(2, 40.0), (1, line_ms + 2.0), (8, 12.0)]), (2, [(5, 0.2), (8, 0.0)]),
+            (30, [(2, 2.0), (3, line_ms - 0.5), (8, 33.0)])]
+    total = sum(n for n, _ in plan)
+    pcm = WL.synth_pcm16(S, B * total, fs, first_stream=11)
+    at = 0
+    for n, reqs in plan:
+        for out, ms in reqs:
+            for x in [d] + o_: assert x.vendor_set(R["SET_OUTPUT_DELAY"], out, f(ms)) == 0
+        part = np.ascontiguousarray(pcm[:, at * B:(at + n) * B])
+        pairs, sub, peaks = d.process_host(part, n, B, tiled=tiled)
+        if tiled: pairs, sub = d.untile(pairs, sub)
+        plan_now = d.launch_plan()
+        assert plan_now["packed_shared"] > 0 and plan_now["latency_layout"] == 0, plan_now
+        for s_ in range(S):
+            rp, rs, rk, _ = o_[s_].process(part[s_], n, B)
+            assert np.array_equal(rp, pairs[s_]), (at, n, s_, np.argwhere(rp != pairs[s_])[:3].tolist())
+            assert np.array_equal(rs, sub[s_]), (at, n, s_, np.argwhere(rs != sub[s_])[:3].tolist())
+            assert np.array_equal(rk, peaks[s_]), (at, n, s_, np.argwhere(rk != peaks[s_])[:3].tolist())
+            assert o_[s_].status() == d.status(s_), (at, n, s_)
+        at += n
+    d.close()
+
+
 @pytest.mark.parametrize("waves", ["4", "7", None])
 def test_q28_wave_layouts(waves, monkeypatch):
     """The Q28 kernel's two wave layouts (four waves: two outputs per wave; seven: one output per wave, for launches of at most one
