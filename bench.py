@@ -466,11 +466,12 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
             pairs = torch.empty((S, P, frames, 2), dtype=torch.int32, device=dev)
             sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
         peaks = torch.empty((S, NB, 2 + N), dtype=torch.int16, device=dev)
+        no_peaks = os.environ.get("DSPI_BENCH_NO_PEAKS") == "1"      # development: the per-packet peak array not requested (traffic accounting)
         torch.cuda.synchronize()
         smi = PowerSampler(dev.index) if check else None
         if smi: smi.start()
         elapsed, kernel_ms = timed_steps(args, torch, dist, backend, dev, ctx,
-                                         lambda: ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled,
+                                         lambda: ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), 0 if no_peaks else peaks.data_ptr(), tiled=tiled,
                                                                     enabled_only=bool(w.get("enabled_only")) if enabled_only is None else enabled_only))
         if smi: smi.stop()
         plan = ctx.launch_plan()
