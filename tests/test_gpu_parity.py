@@ -213,6 +213,38 @@ def test_latency_layout_leveller(flavor, fs, B, depth, lookahead, monkeypatch):
     d.close()
 
 
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+@pytest.mark.parametrize("shape,B,per", [(1, 45, 5), (2, 45, 5), (3, 45, 5), (3, 97, 1), (2, 7, 27), (3, 96, 1)])
+def test_latency_layout_bypassed_bands_keep_their_state(flavor, shape, B, per, monkeypatch):
+    """A bypassed band's state is left alone (dsp_pipeline.c:288-289: `if (bq->bypass) continue`), so REQ_SET_BYPASS on and off again must
+    find the master EQ's filter states where they were.  The latency layout's straight-line step loop updates every lane's state
+    registers, and with zero coefficients an idle lane's s1 changes sign every step: launches with an ODD number of such steps (found by
+    the fuzz sweep at seed 66 once one-packet launches took that loop) wrote the flipped state back.  Every shape, odd and even step
+    counts, one packet per call and many."""
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    fs = 44100 if B == 45 else 48000
+    blob = _latency_blob() if shape == 1 else WL.full_chain_blob(1)
+    if shape == 2: blob["leveller"]["enabled"] = 0
+    S = 5
+    d = Dspi(flavor, S, device=0); o = [Oracle(flavor, detmath=True) for _ in range(S)]
+    for x in [d] + o:
+        assert x.set_rate(fs) == 0
+        x.set_volume(-8 * 256); assert x.load_bulk(blob) == 0
+    seq = [None, 1, None, 0, None, 1, 0, None]      # REQ_SET_BYPASS payloads before each call (None: no request)
+    pcm = WL.synth_pcm16(S, B * per * len(seq), fs, first_stream=4)
+    for k, byp in enumerate(seq):
+        if byp is not None:
+            for x in [d] + o: assert x.vendor_set(W.REQ["SET_BYPASS"], 0, bytes([byp])) == 0
+        part = np.ascontiguousarray(pcm[:, k * B * per:(k + 1) * B * per])
+        pairs, sub, peaks = d.process_host(part, per, B)
+        assert latency_plan(d.launch_plan())
+        for s_ in range(S):
+            rp, rs, rk, _ = o[s_].process(part[s_], per, B)
+            assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (k, s_)
+            assert o[s_].status() == d.status(s_)
+    d.close()
+
+
 @pytest.mark.auto_layout
 @pytest.mark.parametrize("shape", (1, 2, 3))
 @pytest.mark.parametrize("S", (1, 3))
