@@ -1,0 +1,30 @@
+#!/bin/bash
+# tools/final_round.sh <round tag> — the round's closing measurements in one gpurun call: the whole -m gpu suite, smoke(), the default
+# bench line (with the CPU baseline), every other bench configuration, the one-packet-per-call drop-in, small contexts, and the rocprofv3
+# summaries of every kernel (tools/prof_all.sh).  Everything lands under gpurun_out/final_<tag>/ (+ gpurun_out/profsum/), copied to profiles/ by hand.
+R=${1:-r04}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/final_$R; mkdir -p $O
+(time python -m pytest tests -m gpu -q 2>&1 | tail -8) > $O/gputest.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --steps 200 --no-cpu-baseline --no-variants > $O/bench_steps200.json 2>/dev/null
+b() { local name=$1; shift; env "$@" > /dev/null 2>&1; }
+run() { local name=$1; shift; "$@" > $O/bench_$name.json 2>/dev/null; }
+run config_2 python bench.py --config 2 --no-cpu-baseline
+run config_2b python bench.py --config 2b --no-cpu-baseline
+run config_5 python bench.py --config 5 --no-cpu-baseline
+run config_5_64k python bench.py --config 5 --streams 65536 --no-cpu-baseline
+run config3_512streams python bench.py --config 3 --streams 512 --no-cpu-baseline --no-variants
+run perstream python bench.py --config perstream --no-cpu-baseline
+run perstream_eq python bench.py --config perstream_eq --no-cpu-baseline
+DSPI_DEBUG=1 python bench.py --config perstream_eq --no-cpu-baseline > $O/bench_perstream_eq_every_band.json 2>/dev/null
+run pdm python bench.py --config pdm --out-layout tiled
+run spdif python bench.py --config spdif
+run i2s python bench.py --config i2s
+run blocks200_tiled python bench.py --out-layout tiled --blocks-per-step 200 --no-cpu-baseline --no-variants
+python tools/bench_realtime.py --calls 10000 --out $O/realtime.json > $O/realtime.log 2>&1
+python tools/bench_small_contexts.py > $O/small_contexts_leveller_on.jsonl 2>/dev/null
+LEVELLER=0 python tools/bench_small_contexts.py > $O/small_contexts_leveller_off.jsonl 2>/dev/null
+bash tools/prof_all.sh $R > $O/prof_all.log 2>&1
+tail -3 $O/gputest.log; tail -2 $O/smoke.log; ls $O gpurun_out/profsum | head -80

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/prof_all.sh <round tag> — rocprofv3 trace + PMC summaries of every kernel the bench can drive (run via gpurun); the
 # summaries land in gpurun_out/profsum/ and are copied to profiles/ by hand.
-R=${1:-r03}
+R=${1:-r04}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 run() { # tag, bench args, env...
   local tag=$1 args=$2; shift 2
@@ -9,7 +9,7 @@ run() { # tag, bench args, env...
   tail -4 gpurun_out/prof_${R}${tag}.log
 }
 run a "--contract fma --out-layout tiled" CONTRACT=fma OUT_LAYOUT=tiled KERNEL_KEY=chain3 NOTE="config 3, firmware float contract (FMA), tiled words"
-run b "--contract fma --out-layout stream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain3 NOTE="config 3, firmware float contract (FMA), stream-major words through the copy wave: the bench default"
+run b "--contract fma --out-layout stream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain3 NOTE="config 3, firmware float contract (FMA), stream-major words (the delay line as the hand-over between the waves of a pair): the bench default"
 run c "--contract canonical --out-layout tiled" CONTRACT=canonical OUT_LAYOUT=tiled KERNEL_KEY=chain3 NOTE="config 3, canonical contract, tiled words (round-1 configuration)"
 run d "--contract canonical --out-layout stream" CONTRACT=canonical OUT_LAYOUT=stream KERNEL_KEY=chain3 NOTE="config 3, canonical contract, stream-major words"
 run e "--config 5" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=chain5 STREAMS=16384 BLOCK_LEN=48 ALGO_BYTES=56 KERNEL_LIKE="%chain_kernel<0%" NOTE="config 5: Q28 7-channel chain, 16 384 streams, 48 kHz"
