@@ -46,8 +46,8 @@ struct dspi_ctx {
     std::vector<uint32_t> image_item_offset[4];
     // chain launches: the same work lists concatenated over images, grouped by what the kernels are specialised on
     // (float: leveller on/off), so a dspi_process is a handful of launches however many presets are in play
-    std::vector<WgItem> launch_items[2][7];      // [leveller off / on][list]; lists 5, 6: the latency layout (dspi_chain_skew.inc) without / with output rows
-    uint32_t launch_item_offset[2][7] = {};
+    std::vector<WgItem> launch_items[2][9];      // [leveller off / on][list]; lists 5, 6: the latency layout (dspi_chain_skew.inc) without / with output rows;
+    uint32_t launch_item_offset[2][9] = {};      // 7, 8: the same with paired presets (workgroups whose stream slots hold different images of one structure)
     WgItem *d_litems = nullptr; size_t d_litems_cap = 0;
     uint32_t *d_stream_image = nullptr; size_t d_stream_image_cap = 0;   // image index per stream (per-lane parameter kernel)
     bool launch_dirty = true;
@@ -343,7 +343,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
                 if (memcmp(ref->eq, cur->eq, sizeof ref->eq) != 0 || memcmp(ref->loud, cur->loud, sizeof ref->loud) != 0) c->row_pv[it.wg] = 1;
             }
     }
-    for (int lev = 0; lev < 2; lev++) { c->launch_items[lev][5].clear(); c->launch_items[lev][6].clear(); }
+    for (int lev = 0; lev < 2; lev++) for (int k = 5; k <= 8; k++) c->launch_items[lev][k].clear();
     for (int lev = 0; lev < 2; lev++)
         for (int k = 0; k < 5; k++) {
             auto &v = c->launch_items[lev][k];
@@ -413,28 +413,68 @@ int rebuild_launch_lists(dspi_ctx *c) {
         if (h_cls) pairs[h_cls]++;
         bool take[4] = {false, false, false, false};
         for (int cls = 1; cls <= 3; cls++) take[cls] = pairs[cls] > 0 && pairs[cls] <= skew_pair_limit(c->device, cls);
-        // The whole context small — every (lane, image) slot of every class within its limit: EVERY float lane takes the latency layout,
-        // whatever the presets.  A lane whose two streams carry different images runs twice, once per image with the other half inactive
-        // (the kernels store per half): no per-lane-value tiles, no one-stream kernel, any mix of structures.
+        // The whole context small — the lanes of every class within its limit: EVERY float lane takes the latency layout, whatever the
+        // presets: no per-lane-value tiles, no one-stream kernel, any mix of structures.  A workgroup = one part of a row (8 or 2 stream
+        // pairs).  The images that hold streams there: one -> a shared-preset item; several of ONE structure (ImageSig) -> one paired-preset
+        // item (lists 7 / 8: the kernel reads every slot's numbers from its own image, args.stream_image; the item names the first image, for
+        // the structure); several structures -> one item per image, the other images' slots inactive (the kernels store per half).  The
+        // limit counts lanes, a lane of the last kind once per image.  DSPI_SKEW_PAIRED=0 keeps to the last form (development, tests).
         {
+            const char *ppe = getenv("DSPI_SKEW_PAIRED");
+            const bool pp_on = !(ppe && !strcmp(ppe, "0"));
+            struct Slot { uint32_t image; uint64_t m0, m1; };
+            struct Cell { std::vector<Slot> v; bool same = false; };
+            std::map<std::pair<uint32_t, uint32_t>, Cell> cells[4];      // [class]: (row, part) -> images
             uint64_t slots[4] = {0, 0, 0, 0};
-            for (size_t i = 0; i < c->images.size(); i++)
-                if (c->image_refs[i] > 0)
-                    for (const WgItem &it : c->image_items[0][i]) slots[skew_class(c->image_sig[i])] += (uint64_t)__builtin_popcountll(it.mask | it.mask1);
+            {   // a first bound: the lanes in use, whatever their images
+                std::map<uint32_t, uint64_t> used[4];
+                for (size_t i = 0; i < c->images.size(); i++)
+                    if (c->image_refs[i] > 0)
+                        for (const WgItem &it : c->image_items[0][i]) used[skew_class(c->image_sig[i])][it.wg] |= it.mask | it.mask1;
+                for (int cls = 1; cls <= 3; cls++) for (const auto &u : used[cls]) slots[cls] += (uint64_t)__builtin_popcountll(u.second);
+            }
             bool all_small = slots[1] + slots[2] + slots[3] > 0;
             for (int cls = 1; cls <= 3; cls++) if (slots[cls] > skew_pair_limit(c->device, cls)) all_small = false;
             if (all_small) {
-                for (int lev = 0; lev < 2; lev++) for (int k = 1; k <= 4; k++) c->launch_items[lev][k].clear();
                 for (size_t i = 0; i < c->images.size(); i++) {
                     if (c->image_refs[i] == 0) continue;
                     const int cls = skew_class(c->image_sig[i]);
-                    auto &dst = c->launch_items[cls == 3 ? 1 : 0][cls == 2 ? 6 : 5];
                     for (const WgItem &it : c->image_items[0][i])
-                        for (uint32_t ppw = cls == 1 ? 8u : 2u, part = 0; part < 64u / ppw; part++)
-                            if (((it.mask | it.mask1) >> (part * ppw)) & ((1ull << ppw) - 1ull)) dst.push_back(WgItem{it.wg, (uint32_t)i | (part << 26), it.mask, it.mask1});
+                        for (uint32_t ppw = cls == 1 ? 8u : 2u, part = 0; part < 64u / ppw; part++) {
+                            const uint64_t pm = ((1ull << ppw) - 1ull) << (part * ppw);
+                            if ((it.mask | it.mask1) & pm) cells[cls][{it.wg, part}].v.push_back(Slot{(uint32_t)i, it.mask & pm, it.mask1 & pm});
+                        }
                 }
+                for (int cls = 1; cls <= 3; cls++) {
+                    slots[cls] = 0;
+                    for (auto &cell : cells[cls]) {
+                        std::vector<Slot> &v = cell.second.v;
+                        bool same = pp_on && v.size() > 1;
+                        for (size_t j = 1; same && j < v.size(); j++)
+                            if (memcmp(&c->image_sig[v[0].image], &c->image_sig[v[j].image], sizeof(dspi_ctx::ImageSig)) != 0) same = false;
+                        cell.second.same = same;
+                        uint64_t u = 0;
+                        for (const Slot &sl : v) { if (same) u |= sl.m0 | sl.m1; else slots[cls] += (uint64_t)__builtin_popcountll(sl.m0 | sl.m1); }
+                        slots[cls] += (uint64_t)__builtin_popcountll(u);
+                    }
+                    if (slots[cls] > skew_pair_limit(c->device, cls)) all_small = false;
+                }
+            }
+            if (all_small) {
+                for (int lev = 0; lev < 2; lev++) for (int k = 1; k <= 4; k++) c->launch_items[lev][k].clear();
+                for (int cls = 1; cls <= 3; cls++)
+                    for (const auto &cell : cells[cls]) {
+                        const uint32_t row = cell.first.first, part = cell.first.second;
+                        const std::vector<Slot> &v = cell.second.v;
+                        if (cell.second.same) {
+                            uint64_t m0 = 0, m1 = 0;
+                            for (const Slot &sl : v) { m0 |= sl.m0; m1 |= sl.m1; }
+                            c->launch_items[cls == 3 ? 1 : 0][cls == 2 ? 8 : 7].push_back(WgItem{row, v[0].image | (part << 26), m0, m1});
+                        } else
+                            for (const Slot &sl : v) c->launch_items[cls == 3 ? 1 : 0][cls == 2 ? 6 : 5].push_back(WgItem{row, sl.image | (part << 26), sl.m0, sl.m1});
+                    }
                 for (int lev = 0; lev < 2; lev++)
-                    for (int k = 5; k <= 6; k++)
+                    for (int k = 5; k <= 8; k++)
                         std::stable_sort(c->launch_items[lev][k].begin(), c->launch_items[lev][k].end(), [](const WgItem &x, const WgItem &y) { return x.wg < y.wg; });
                 take[1] = take[2] = take[3] = false;      // (nothing left for the shared-preset rule below)
             }
@@ -476,7 +516,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
         }
     }
     for (int lev = 0; lev < 2; lev++)
-        for (int k = 0; k < 7; k++) {
+        for (int k = 0; k < 9; k++) {
             c->launch_item_offset[lev][k] = (uint32_t)total;
             total += c->launch_items[lev][k].size();
         }
@@ -485,7 +525,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
     if ((rc = ensure(c, c->d_stream_image, c->d_stream_image_cap, (size_t)c->n_streams * 4))) return rc;
     HIPCK(c, hipStreamSynchronize(c->hs));      // no launch may still be reading the lists we overwrite
     for (int lev = 0; lev < 2; lev++)
-        for (int k = 0; k < 7; k++)
+        for (int k = 0; k < 9; k++)
             if (!c->launch_items[lev][k].empty())
                 HIPCK(c, hipMemcpy(c->d_litems + c->launch_item_offset[lev][k], c->launch_items[lev][k].data(),
                                    c->launch_items[lev][k].size() * sizeof(WgItem), hipMemcpyHostToDevice));
@@ -816,9 +856,10 @@ int dspi_debug_image(dspi_ctx *c, int32_t stream, void *buf, size_t cap) {
 
 int dspi_debug_launch_plan(dspi_ctx *c, uint32_t *counts, size_t n_counts) {
     if (!c || !counts || n_counts < 5) return DSPI_E_INVAL;
-    const int n = n_counts >= 6 ? 6 : 5;      // [5]: items of the latency layout (dspi_chain_skew.inc)
-    for (int k = 0; k < n; k++) counts[k] = (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size());
-    if (n == 6) counts[5] += (uint32_t)(c->launch_items[0][6].size() + c->launch_items[1][6].size());      // every shape of the latency layout
+    const int n = n_counts >= 7 ? 7 : n_counts >= 6 ? 6 : 5;      // [5]: items of the latency layout (dspi_chain_skew.inc), [6]: those of them with paired presets
+    for (int k = 0; k < 5; k++) counts[k] = (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size());
+    if (n >= 6) { counts[5] = 0; for (int k = 5; k <= 8; k++) counts[5] += (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size()); }      // every shape of the latency layout
+    if (n >= 7) { counts[6] = 0; for (int k = 7; k <= 8; k++) counts[6] += (uint32_t)(c->launch_items[0][k].size() + c->launch_items[1][k].size()); }
     if (c->flavor) counts[0] = 0;      // (list 0 of a float context is bookkeeping for the state mutations, never launched)
     return n;
 }
@@ -1073,10 +1114,10 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     // per-lane-parameter kernel for both lane components in one launch (list 2).  Q28: rows with one image run workgroup-uniform
     // (list 0), rows with several in per-lane-parameter mode (list 2).  A launch covers every image.
     struct Launch { int list; int packed; };
-    static const Launch kF32[] = {{1, 1}, {5, 5}, {6, 6}, {3, 3}, {4, 4}, {2, 2}};      // lists 3 / 4: per-lane-value rows (packed kernel + value tiles); 5 / 6: latency layout
+    static const Launch kF32[] = {{1, 1}, {5, 5}, {6, 6}, {7, 7}, {8, 8}, {3, 3}, {4, 4}, {2, 2}};      // lists 3 / 4: per-lane-value rows (packed kernel + value tiles); 5 - 8: latency layout
     static const Launch kQ28[] = {{0, 0}, {2, 2}};
     const Launch *ls = c->flavor ? kF32 : kQ28;
-    const int nl = c->flavor ? 6 : 2;
+    const int nl = c->flavor ? 8 : 2;
     a.vals = c->d_vals;
     // the chain launches for the rows [r0, r1) (the lists are sorted by row)
     auto launch_rows_1 = [&](uint32_t r0, uint32_t r1) -> int {

@@ -1623,7 +1623,8 @@ DSPI_PK_FAMILY(5, true, true, true)
 
 // the latency layout of the float chain (dspi_chain_skew.inc): part 7
 hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream);
-#if !defined(DSPI_PART) || DSPI_PART == 7
+hipError_t launch_chain_skew_pp(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream);
+#if !defined(DSPI_PART) || DSPI_PART == 7 || DSPI_PART == 8
 // one launcher for the instances of a shape: float contract x input word size, with or without the S/PDIF encoder in the output waves
 template <class F>
 static hipError_t sk_launch(const KArgs &args, dim3 grid, dim3 block, size_t lds, hipStream_t stream, bool (&attr_set)[kMaxDevices], F kernels) {
@@ -1641,22 +1642,32 @@ static hipError_t sk_launch(const KArgs &args, dim3 grid, dim3 block, size_t lds
     return hipGetLastError();
 }
 typedef void (*SkKernel)(KArgs);
-template <bool EQO>
+template <bool EQO, bool PP>
 static hipError_t launch_chain_skew_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     static bool attr_set[kMaxDevices] = {};
-    static const SkKernel k[8] = {chain_kernel_skew<false, false, EQO, false>, chain_kernel_skew<false, false, EQO, true>, chain_kernel_skew<false, true, EQO, false>, chain_kernel_skew<false, true, EQO, true>,
-                                  chain_kernel_skew<true, false, EQO, false>, chain_kernel_skew<true, false, EQO, true>, chain_kernel_skew<true, true, EQO, false>, chain_kernel_skew<true, true, EQO, true>};
+    static const SkKernel k[8] = {chain_kernel_skew<false, false, EQO, false, PP>, chain_kernel_skew<false, false, EQO, true, PP>, chain_kernel_skew<false, true, EQO, false, PP>, chain_kernel_skew<false, true, EQO, true, PP>,
+                                  chain_kernel_skew<true, false, EQO, false, PP>, chain_kernel_skew<true, false, EQO, true, PP>, chain_kernel_skew<true, true, EQO, false, PP>, chain_kernel_skew<true, true, EQO, true, PP>};
     return sk_launch(args, dim3(n_items), dim3(64 * kSkWaves), sizeof(SkShared<EQO>), stream, attr_set, k);
 }
+template <bool PP>
 static hipError_t launch_chain_skew_lev(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     static bool attr_set[kMaxDevices] = {};
-    static const SkKernel k[8] = {chain_kernel_skew_lev<false, false, false>, chain_kernel_skew_lev<false, false, true>, chain_kernel_skew_lev<false, true, false>, chain_kernel_skew_lev<false, true, true>,
-                                  chain_kernel_skew_lev<true, false, false>, chain_kernel_skew_lev<true, false, true>, chain_kernel_skew_lev<true, true, false>, chain_kernel_skew_lev<true, true, true>};
+    static const SkKernel k[8] = {chain_kernel_skew_lev<false, false, false, PP>, chain_kernel_skew_lev<false, false, true, PP>, chain_kernel_skew_lev<false, true, false, PP>, chain_kernel_skew_lev<false, true, true, PP>,
+                                  chain_kernel_skew_lev<true, false, false, PP>, chain_kernel_skew_lev<true, false, true, PP>, chain_kernel_skew_lev<true, true, false, PP>, chain_kernel_skew_lev<true, true, true, PP>};
     return sk_launch(args, dim3(n_items), dim3(64 * kSlWaves), sizeof(SlShared), stream, attr_set, k);
 }
+#endif
+#if !defined(DSPI_PART) || DSPI_PART == 7
 hipError_t launch_chain_skew(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream) {      // shape 1 / 2 / 3: dspi_capi.cpp skew_class
-    if (shape == 3) return launch_chain_skew_lev(args, n_items, stream);
-    return shape == 2 ? launch_chain_skew_t<true>(args, n_items, stream) : launch_chain_skew_t<false>(args, n_items, stream);
+    if (shape == 3) return launch_chain_skew_lev<false>(args, n_items, stream);
+    return shape == 2 ? launch_chain_skew_t<true, false>(args, n_items, stream) : launch_chain_skew_t<false, false>(args, n_items, stream);
+}
+#endif
+#if !defined(DSPI_PART) || DSPI_PART == 8
+// ... with paired presets (every stream slot of a workgroup its own image of one structure, dspi_chain_skew.inc SkNum): part 8
+hipError_t launch_chain_skew_pp(const KArgs &args, uint32_t n_items, int shape, hipStream_t stream) {
+    if (shape == 3) return launch_chain_skew_lev<true>(args, n_items, stream);
+    return shape == 2 ? launch_chain_skew_t<true, true>(args, n_items, stream) : launch_chain_skew_t<false, true>(args, n_items, stream);
 }
 #endif
 
@@ -1720,6 +1731,7 @@ hipError_t launch_chain(int flavor, int packed, bool leveller_on, const KArgs &a
     if (!flavor) return packed == 2 ? launch_chain_t<0, true>(args, n_items, stream) : launch_chain_t<0, false>(args, n_items, stream);
     // float: the context's contract (DSPI_FLOAT_CONTRACT_FMA) picks the kernel family
     if (packed == 5 || packed == 6) return launch_chain_skew(args, n_items, leveller_on ? 3 : (packed == 6 ? 2 : 1), stream);
+    if (packed == 7 || packed == 8) return launch_chain_skew_pp(args, n_items, leveller_on ? 3 : (packed == 8 ? 2 : 1), stream);
     if (packed != 1 && packed != 3 && packed != 4) return args.fma ? launch_chain_t<1, false, true>(args, n_items, stream) : launch_chain_t<1, false, false>(args, n_items, stream);
     if (packed == 3) return args.fma ? launch_chain_pk_f5(args, leveller_on, n_items, stream) : launch_chain_pk_f2(args, leveller_on, n_items, stream);
     if (packed == 4) return args.fma ? launch_chain_pk_f4(args, leveller_on, n_items, stream) : launch_chain_pk_f1(args, leveller_on, n_items, stream);

@@ -194,9 +194,10 @@ class Dspi:
 
     def launch_plan(self) -> dict:
         """dspi_debug_launch_plan: work items per kernel path after the last process call."""
-        c = (C.c_uint32 * 6)()
-        self._ck(min(self.L.dspi_debug_launch_plan(self.h, c, 6), 0), "debug_launch_plan")
-        return dict(zip(("q28_shared", "packed_shared", "one_stream_per_lane_images", "packed_per_lane_values_and_bands", "packed_per_lane_values", "latency_layout"), list(c)))
+        c = (C.c_uint32 * 7)()
+        self._ck(min(self.L.dspi_debug_launch_plan(self.h, c, 7), 0), "debug_launch_plan")
+        return dict(zip(("q28_shared", "packed_shared", "one_stream_per_lane_images", "packed_per_lane_values_and_bands", "packed_per_lane_values", "latency_layout",
+                         "latency_layout_paired"), list(c)))
 
     def image_count(self) -> int:
         """dspi_debug_image_count: distinct parameter objects held (equal ones are folded after broadcast calls)."""

@@ -257,7 +257,9 @@ int dspi_debug_image(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
  * {Q28 shared image, packed float shared image, one-stream kernel with per-lane parameter images, packed float with per-lane values
  * incl. band coefficients, packed float with per-lane values and shared band coefficients}.  Tests use it to prove that a scenario
  * ran on the path it was written for.  With n_counts >= 6, counts[5] = items of the float chain's latency layout (any of its three
- * shapes: launches of shared-preset rows small enough to leave the chip underfilled).  Returns the number of counts written (5 or 6) or a negative DSPI_E_*. */
+ * shapes: launches small enough to leave the chip underfilled); with n_counts >= 7, counts[6] = those of them that serve several
+ * presets of one structure at once (a workgroup's stream slots each read their own image).  Returns the number of counts written
+ * (5, 6 or 7) or a negative DSPI_E_*. */
 int dspi_debug_launch_plan(dspi_ctx *ctx, uint32_t *counts, size_t n_counts);
 /* Number of distinct parameter objects the context holds (streams share one until a per-stream call separates them; streams that
  * received the same whole state again through broadcast calls are folded back, here or at the next dspi_process).  Works on

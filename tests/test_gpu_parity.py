@@ -616,13 +616,91 @@ def test_one_structure_different_numbers(fma, fs, B, depth, S, lev):
         rows = (S + 127) // 128
         # row 0 holds the stream of another structure: it runs on the one-stream kernel; every other row is a per-lane-value row with
         # per-lane filters; an odd last stream adds one more one-stream item
-        if on_latency_layout(): assert latency_plan(plan), plan
+        # ... on the latency layout: paired presets — a workgroup's stream slots each read their own image (two pairs per workgroup here:
+        # a workgroup per four streams, plus the ones the stream of another structure splits)
+        # (not all of them: a UAC1 volume can switch a loudness shelf on or off, which is structure — such a workgroup runs once per image)
+        if on_latency_layout(): assert latency_plan(plan) and plan["latency_layout_paired"] >= (S + 3) // 4 * 3 // 4, plan
         else: assert plan["packed_per_lane_values_and_bands"] == rows - 1 and plan["one_stream_per_lane_images"] >= 1 and plan["packed_shared"] == 0, plan
         for s_ in range(S):
             rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B, depth)
             assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (call, s_)
             assert o[s_].status() == d.status(s_)
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+@pytest.mark.parametrize("shape,fs,B,depth,S", [(1, 48000, 48, 16, 70), (1, 44100, 45, 24, 37), (2, 96000, 96, 16, 70), (3, 96000, 96, 16, 70), (3, 48000, 7, 24, 21), (1, 48000, 1, 16, 33)])
+def test_latency_layout_paired_presets(flavor, shape, fs, B, depth, S, monkeypatch):
+    """Verdict r03 item 7: a small context in which every stream has a preset of its own, all of one structure.  The latency layout used to
+    give each of them a workgroup (the other stream slots idle); now a workgroup's slots each read their own image (dspi_chain_skew.inc
+    SkNum): sixteen (shape 1) or four (shapes 2, 3) presets per workgroup.  All three shapes, numbers that differ wherever the shape reads
+    one (master bands, preamps, volumes, crosspoint and output gains, output bands, leveller and crossfeed constants), against every
+    stream's own oracle over two calls with changes in between; DSPI_SKEW_PAIRED=0 (one workgroup per preset, the old form) must give
+    the same words."""
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    blocks = 5
+    blob = _latency_blob() if shape == 1 else WL.full_chain_blob(1)
+    blob["leveller"]["enabled"] = 1 if shape == 3 else 0
+    R = W.REQ
+    f = lambda v: struct.pack("<f", v)
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs)
+    data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm)
+    per = B * blocks * (1 if depth == 16 else 6)
+
+    def numbers(rng, s_, call):
+        reqs = [(R["SET_PREAMP_CH"], 0, f(-15.0 + 0.05 * s_)), (R["SET_PREAMP_CH"], 1, f(-14.0 - 0.03 * s_)), (R["SET_MASTER_VOLUME"], 0, f(-0.1 * (s_ % 40) - call))]
+        for _ in range(8):        # same type and frequency (the kind depends on both), new gain and Q
+            ch, band = int(rng.integers(0, 2 if shape == 1 else 11)), int(rng.integers(0, 10))
+            p = blob["eq"][ch][band]
+            if int(p["type"]) == W.FILTER_FLAT: continue
+            reqs.append((R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, band, int(p["type"]), 0, float(p["freq"]), float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 9.0)) * (1.0 if rng.random() < 0.5 else -1.0))))
+        reqs.append((R["SET_OUTPUT_GAIN"], int(rng.integers(0, 9)), f(float(rng.uniform(-12, 3)))))
+        for i_ in range(2):       # a routed crosspoint keeps a non-zero gain (its zero pattern is structure)
+            o2 = int(rng.integers(0, 9))
+            xp = blob["crosspoints"][i_][o2]
+            if int(xp["enabled"]): reqs.append((R["SET_MATRIX_ROUTE"], 0, struct.pack("<BBBBf", i_, o2, 1, int(xp["phase_invert"]), float(rng.uniform(-9, 0)))))
+        if shape == 3:
+            reqs += [(R["SET_LEVELLER_AMOUNT"], 0, f(float(rng.uniform(10, 100)))), (R["SET_LEVELLER_SPEED"], 0, bytes([int(rng.integers(0, 3))])),
+                     (R["SET_LEVELLER_MAX_GAIN"], 0, f(float(rng.uniform(3, 20)))), (R["SET_LEVELLER_GATE"], 0, f(float(rng.uniform(-90, -50))))]
+        if int(blob["crossfeed"]["enabled"]):
+            reqs += [(R["SET_CROSSFEED_PRESET"], 0, b"\x03"), (R["SET_CROSSFEED_FREQ"], 0, f(float(rng.uniform(500, 1500)))), (R["SET_CROSSFEED_FEED"], 0, f(float(rng.uniform(3, 12))))]
+        return reqs
+
+    results = {}
+    for paired in ("1", "0"):
+        monkeypatch.setenv("DSPI_SKEW_PAIRED", paired)
+        rng = np.random.default_rng(5 + S)
+        d = Dspi(flavor, S, device=0)
+        o = [Oracle(flavor, detmath=True) for _ in range(S)] if paired == "1" else []
+        for x in [d] + o:
+            x.set_rate(fs); x.set_volume(-9 * 256); assert x.load_bulk(blob) == 0
+        out = []
+        for call in range(2):
+            for s_ in range(S):
+                if call == 1 and s_ % 3: continue
+                for req, wv, pl in numbers(rng, s_, call):
+                    assert d.vendor_set(req, wv, pl, stream=s_) == 0
+                    if o: assert o[s_].vendor_set(req, wv, pl) == 0
+            chunk = np.ascontiguousarray(data[:, call * per:(call + 1) * per])
+            pairs, sub, peaks = d.process_host(chunk, blocks, B, depth, clip=True)
+            plan = d.launch_plan()
+            ppw = 16 if shape == 1 else 4
+            wgs = sum((min(S, r + 128) - r + ppw - 1) // ppw for r in range(0, S, 128))
+            alone = 1 if S % ppw == 1 else 0        # a last workgroup that holds ONE stream is a shared-preset item
+            assert latency_plan(plan), plan
+            if paired == "1": assert plan["latency_layout"] == wgs and plan["latency_layout_paired"] == wgs - alone, (plan, wgs)
+            else: assert plan["latency_layout_paired"] == 0 and plan["latency_layout"] == S, plan
+            assert d.image_count() == S
+            for s_ in range(S if o else 0):
+                rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B, depth)
+                assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (call, s_)
+                assert o[s_].status() == d.status(s_)
+            out.append((pairs.copy(), sub.copy(), peaks.copy(), d.last_clip.copy()))
+        results[paired] = out
+        d.close()
+    for a_, b_ in zip(results["1"], results["0"]):
+        for x_, y_ in zip(a_, b_): assert np.array_equal(x_, y_)
 
 
 @pytest.mark.both_layouts
