@@ -31,12 +31,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     for _ in range(3): d.process_device(pcm.data_ptr(), blocks, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr())
     d.sync(); dt = (time.perf_counter() - t0) / 3
     plan = d.launch_plan()
-    print(json.dumps({"streams": S, "layout": "latency" if plan["latency_layout"] else "packed", "forced": os.environ.get("DSPI_F32_LAYOUT", ""), "per_stream_presets": bool(os.environ.get("PERSTREAM")), "ms_per_launch": dt * 1e3,
+    print(json.dumps({"streams": S, "layout": "latency" if plan["latency_layout"] else "packed", "forced": os.environ.get("DSPI_F32_LAYOUT", ""), "per_stream_presets": bool(os.environ.get("PERSTREAM")),
+                      "workgroups": plan["latency_layout"], "workgroups_with_paired_presets": plan["latency_layout_paired"], "ms_per_launch": dt * 1e3,
                       "frames_per_s": S * FR / dt, "realtime_x_per_stream": FR / fs / dt}))
     sys.exit(0)
-for S in (1, 2, 16, 128, 512, 1024, 2048, 4096, 8192):
-    for lay in ("", "skew", "packed"):
+SIZES = [int(x) for x in os.environ.get("SIZES", "1,2,16,128,512,1024,2048,4096,8192").split(",")]
+# PERSTREAM=1 adds a run with DSPI_SKEW_PAIRED=0: one workgroup per preset, the form before the slots of a workgroup read their own images
+for S in SIZES:
+    for lay in ("", "skew", "packed") + (("unpaired",) if os.environ.get("PERSTREAM") else ()):
         env = dict(os.environ)
-        if lay: env["DSPI_F32_LAYOUT"] = lay
+        if lay == "unpaired": env["DSPI_F32_LAYOUT"] = "skew"; env["DSPI_SKEW_PAIRED"] = "0"
+        elif lay: env["DSPI_F32_LAYOUT"] = lay
         out = subprocess.run([sys.executable, __file__, "child", str(S)], env=env, capture_output=True, text=True).stdout.strip().split("\n")[-1]
         print(out, flush=True)

@@ -26,5 +26,7 @@ run blocks200_tiled python bench.py --out-layout tiled --blocks-per-step 200 --n
 python tools/bench_realtime.py --calls 10000 --out $O/realtime.json > $O/realtime.log 2>&1
 python tools/bench_small_contexts.py > $O/small_contexts_leveller_on.jsonl 2>/dev/null
 LEVELLER=0 python tools/bench_small_contexts.py > $O/small_contexts_leveller_off.jsonl 2>/dev/null
+SIZES=16,128,512,1024,2048,4096 PERSTREAM=1 python tools/bench_small_contexts.py > $O/small_contexts_per_stream_leveller_on.jsonl 2>/dev/null
+SIZES=512,1024,2048,4096 LEVELLER=0 PERSTREAM=1 python tools/bench_small_contexts.py > $O/small_contexts_per_stream_leveller_off.jsonl 2>/dev/null
 bash tools/prof_all.sh $R > $O/prof_all.log 2>&1
 tail -3 $O/gputest.log; tail -2 $O/smoke.log; ls $O gpurun_out/profsum | head -80
