@@ -1126,17 +1126,23 @@ def test_i2s_slot_words_fused_into_the_chain(flavor, tiled, monkeypatch):
         plain.close(); fused.close()
 
 
+@pytest.mark.parametrize("distinct", (False, True), ids=("shared", "paired"))
 @pytest.mark.parametrize("shape,fs,B", [(1, 48000, 48), (2, 96000, 96), (3, 44100, 45), (3, 48000, 7)])
-def test_spdif_subframes_fused_into_the_chain(shape, fs, B, monkeypatch):
+def test_spdif_subframes_fused_into_the_chain(shape, fs, B, distinct, monkeypatch):
     """DSPI_OUT_SPDIF: the latency layout's output waves write the IEC 60958 subframes themselves — every shape of the layout, three calls
     so that the block position runs across call boundaries (and a set position) — the words dspi_process + dspi_spdif_encode give, which
-    test_spdif_subframes pins to the reference's spdif_update_subframe.  A launch that is not on the latency layout refuses the flag."""
+    test_spdif_subframes pins to the reference's spdif_update_subframe.  A launch that is not on the latency layout refuses the flag.
+    `paired`: every stream a preset of its own (one structure): the paired-preset instances of the kernels, with the encoder."""
     monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
     blob = _latency_blob() if shape == 1 else WL.full_chain_blob(1)
     if shape == 2: blob["leveller"]["enabled"] = 0
     blocks, S = (16 if B >= 44 else 120), 9
     plain, fused = Dspi(W.F32_FMA, S, device=0), Dspi(W.F32_FMA, S, device=0)
-    for d in (plain, fused): d.set_rate(fs); d.set_volume(-6 * 256); assert d.load_bulk(blob) == 0
+    for d in (plain, fused):
+        d.set_rate(fs); d.set_volume(-6 * 256); assert d.load_bulk(blob) == 0
+        for s_ in range(S if distinct else 0):
+            assert d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.25 * s_), stream=s_) == 0
+            assert d.vendor_set(W.REQ["SET_OUTPUT_GAIN"], s_ % 9, struct.pack("<f", -1.0 - 0.5 * s_), stream=s_) == 0
     assert fused.spdif_block_pos(77) == 77
     pos = 77
     pcm = WL.synth_pcm16(S, B * blocks * 3, fs)
@@ -1145,7 +1151,7 @@ def test_spdif_subframes_fused_into_the_chain(shape, fs, B, monkeypatch):
         p0, s0, k0 = plain.process_host(part, blocks, B)
         want, nxt = plain.spdif_host(p0, pos)
         p1, s1, k1 = fused.process_host(part, blocks, B, spdif=True)
-        assert fused.launch_plan()["latency_layout"] > 0
+        assert fused.launch_plan()["latency_layout"] > 0 and (fused.launch_plan()["latency_layout_paired"] > 0) == distinct
         assert np.array_equal(p1, want), (c, np.argwhere(p1 != want)[:4].tolist())
         assert np.array_equal(s1, s0) and np.array_equal(k1, k0), c
         pos = nxt

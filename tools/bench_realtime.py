@@ -19,9 +19,18 @@ from orclib import Oracle
 HOST = os.path.join(ROOT, "dspi_amd", "csrc", "dspi_host")
 
 
-def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None):
-    fl = int(flavor)
+def preset_blob(fl, preset):
+    """config3: BASELINE config 3 (the latency layout's third shape on small float contexts); config3_leveller_off: its second shape;
+    config2: master PEQ only (BASELINE config 2's preset: the first shape)."""
+    if preset == "config2": return WL.config2_blob(False) if fl else WL.full_chain_blob(fl)
     blob = WL.full_chain_blob(fl)
+    if preset == "config3_leveller_off": blob["leveller"]["enabled"] = 0
+    return blob
+
+
+def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None, preset="config3"):
+    fl = int(flavor)
+    blob = preset_blob(fl, preset)
     pcm = WL.synth_pcm16(1, B * packets, fs, first_stream=3)[0]           # the file every stream plays (stream s is s packets behind)
     ref = Oracle(fl); assert ref.load_bulk(blob) == 0
     with tempfile.TemporaryDirectory() as td:
@@ -34,7 +43,7 @@ def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None):
         line = [l for l in r.stdout.splitlines() if l.startswith("rt:")][0]
         m = re.search(r"p50 ([\d.]+) us\s+p99 ([\d.]+) us\s+p99.9 ([\d.]+) us\s+max ([\d.]+) us\s+\(first (\d+) calls: max ([\d.]+) us\)\s+mean ([\d.]+) us = ([\d.]+) x real time", line)
         rec = dict(flavor=flavor_name, streams=S, fs=fs, block_len=B, calls=calls, p50_us=float(m.group(1)), p99_us=float(m.group(2)), p999_us=float(m.group(3)), max_us=float(m.group(4)),
-                   first_calls=int(m.group(5)), first_calls_max_us=float(m.group(6)), mean_us=float(m.group(7)), realtime_x=float(m.group(8)), packet_us=B / fs * 1e6)
+                   preset=preset, first_calls=int(m.group(5)), first_calls_max_us=float(m.group(6)), mean_us=float(m.group(7)), realtime_x=float(m.group(8)), packet_us=B / fs * 1e6)
         lat = np.fromfile(os.path.join(td, "lat.f64"), dtype=np.float64)
         rec["over_packet_time"] = int((lat[rec["first_calls"]:] > B / fs).sum())      # calls (steady state) that took longer than the packet they carry
         if check:
@@ -67,13 +76,15 @@ def main():
     ap.add_argument("--flavors", default="f32fma,q28")
     ap.add_argument("--out", default="")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--presets", default="config3", help="comma list of config3, config3_leveller_off, config2 (float flavours)")
     a = ap.parse_args()
     recs = []
     for fname in a.flavors.split(","):
         flavor = {"f32fma": W.F32_FMA, "f32": 1, "q28": 0}[fname]
         fs, B = (96000, 96) if int(flavor) else (48000, 48)
-        for S in [int(x) for x in a.streams.split(",")]:
-            recs.append(run(fname, flavor, S, fs, B, a.calls, 1000, check=not a.no_check))
+        for preset in (a.presets.split(",") if int(flavor) else ["config3"]):
+            for S in [int(x) for x in a.streams.split(",")]:
+                recs.append(run(fname, flavor, S, fs, B, a.calls, 1000, check=not a.no_check, preset=preset))
     if a.out:
         json.dump({"what": "dspi_host -rt: one packet per dspi_process(), host buffers, back to back (tools/bench_realtime.py)", "runs": recs}, open(a.out, "w"), indent=1)
 

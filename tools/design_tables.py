@@ -76,7 +76,7 @@ def realtime():
     rows = json.load(open(path))["runs"]
     out = ["| context | calls | p50 us | p99 us | max us | bit-exact |", "|---|---|---|---|---|---|"]
     for r in rows:
-        out.append(f"| {r['flavor']}, {r['streams']} stream(s), {r['block_len']} frames at {r['fs']} Hz | {r['calls']} | {r['p50_us']:.1f} | {r['p99_us']:.1f} | "
+        out.append(f"| {r['flavor']}, {r.get('preset', 'config3')}, {r['streams']} stream(s), {r['block_len']} frames at {r['fs']} Hz | {r['calls']} | {r['p50_us']:.1f} | {r['p99_us']:.1f} | "
                    f"{r['max_us']:.0f} | {r['parity']} |")
     return "\n".join(out)
 

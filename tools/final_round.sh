@@ -23,7 +23,7 @@ run pdm python bench.py --config pdm --out-layout tiled
 run spdif python bench.py --config spdif
 run i2s python bench.py --config i2s
 run blocks200_tiled python bench.py --out-layout tiled --blocks-per-step 200 --no-cpu-baseline --no-variants
-python tools/bench_realtime.py --calls 10000 --out $O/realtime.json > $O/realtime.log 2>&1
+python tools/bench_realtime.py --calls 10000 --presets config3,config3_leveller_off,config2 --out $O/realtime.json > $O/realtime.log 2>&1
 python tools/bench_small_contexts.py > $O/small_contexts_leveller_on.jsonl 2>/dev/null
 LEVELLER=0 python tools/bench_small_contexts.py > $O/small_contexts_leveller_off.jsonl 2>/dev/null
 SIZES=16,128,512,1024,2048,4096 PERSTREAM=1 python tools/bench_small_contexts.py > $O/small_contexts_per_stream_leveller_on.jsonl 2>/dev/null
