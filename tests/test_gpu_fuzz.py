@@ -237,3 +237,68 @@ def test_random_preset_per_stream(flavor, seed):
         assert o.status() == d.status(s), f"stream {s}: status"
         o.close()
     d.close()
+
+
+@pytest.mark.all_layouts
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 8))))
+def test_random_numbers_one_random_structure(flavor, seed):
+    """One random preset for everybody, then every stream changes NUMBERS in it — band gains and Q at the band's own type and frequency,
+    preamps, master volume, output gains, the gains of routed crosspoints, leveller amount / speed / max gain / gate, crossfeed — so that
+    most workgroups hold several presets of one structure: paired presets on the latency layout (dspi_chain_skew.inc SkNum: a workgroup's
+    stream slots each read their own image), value tiles on the packed kernel.  Where a number does change the structure (a band gone
+    flat, a loudness shelf switched by the volume) the workgroup runs once per image: either way every sampled stream must equal its
+    own oracle over two launches, with more changes in between."""
+    import struct
+    from dspi_amd.host import Dspi
+    from dspi_amd import workloads as WL
+    from orclib import Oracle
+    rng = np.random.default_rng(9900 + 100 * flavor + seed)
+    fs, Bs = RATES[seed % 3]
+    B = int(rng.choice(list(Bs) + [1, 7])); blocks = int(rng.integers(3, 9)); S = int(rng.choice([7, 33, 70, 140]))
+    depth = 16 if rng.random() < 0.5 else 24
+    blob = random_blob(rng, flavor, fs)
+    R = W.REQ
+    f = lambda v: struct.pack("<f", v)
+    watch = sorted(set(int(x) for x in rng.integers(0, S, 10)) | {0, S - 1})
+    d = Dspi(flavor, S, device=0); o = {s_: Oracle(flavor, detmath=True) for s_ in watch}
+    for x in [d] + list(o.values()):
+        assert x.set_rate(fs) == 0; x.set_volume(-6 * 256); assert x.load_bulk(blob) == 0
+
+    def numbers():
+        reqs = [(R["SET_PREAMP_CH"], 0, f(float(rng.uniform(-12, 3)))), (R["SET_PREAMP_CH"], 1, f(float(rng.uniform(-12, 3)))), (R["SET_MASTER_VOLUME"], 0, f(float(rng.uniform(-20, 0))))]
+        for _ in range(int(rng.integers(2, 10))):
+            ch, band = int(rng.integers(0, 11)), int(rng.integers(0, 10))
+            p_ = blob["eq"][ch][band]
+            if int(p_["type"]) == W.FILTER_FLAT: continue
+            reqs.append((R["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, band, int(p_["type"]), 0, float(p_["freq"]), float(rng.uniform(0.3, 4.0)), float(rng.uniform(0.5, 11.0)) * (1.0 if rng.random() < 0.5 else -1.0))))
+        for _ in range(2): reqs.append((R["SET_OUTPUT_GAIN"], int(rng.integers(0, 9)), f(float(rng.uniform(-18, 5)))))
+        for _ in range(3):
+            i_, o2 = int(rng.integers(0, 2)), int(rng.integers(0, 9))
+            xp = blob["crosspoints"][i_][o2]
+            if int(xp["enabled"]): reqs.append((R["SET_MATRIX_ROUTE"], 0, struct.pack("<BBBBf", i_, o2, 1, int(xp["phase_invert"]), float(rng.uniform(-15, 2)))))
+        if int(blob["leveller"]["enabled"]):
+            reqs += [(R["SET_LEVELLER_AMOUNT"], 0, f(float(rng.uniform(5, 100)))), (R["SET_LEVELLER_SPEED"], 0, bytes([int(rng.integers(0, 3))])),
+                     (R["SET_LEVELLER_MAX_GAIN"], 0, f(float(rng.uniform(1, 22)))), (R["SET_LEVELLER_GATE"], 0, f(float(rng.uniform(-90, -45))))]
+        if int(blob["crossfeed"]["enabled"]) and rng.random() < 0.7:
+            reqs += [(R["SET_CROSSFEED_PRESET"], 0, b"\x03"), (R["SET_CROSSFEED_FREQ"], 0, f(float(rng.uniform(500, 1500)))), (R["SET_CROSSFEED_FEED"], 0, f(float(rng.uniform(3, 12))))]
+        return reqs
+
+    pcm = WL.synth_pcm16(S, B * blocks * 2, fs, first_stream=int(rng.integers(0, 20)))
+    data = pcm if depth == 16 else WL.pcm16_to_pcm24_bytes(pcm)
+    step = blocks * B * (1 if depth == 16 else 6)
+    for c in range(2):
+        for s_ in range(S):
+            if c == 1 and rng.random() < 0.6: continue
+            for req, wv, pl in numbers():
+                rc = d.vendor_set(req, wv, pl, stream=s_)
+                if s_ in o: assert o[s_].vendor_set(req, wv, pl) == rc
+        chunk = np.ascontiguousarray(data[:, c * step:(c + 1) * step])
+        pairs, sub, peaks = d.process_host(chunk, blocks, B, depth)
+        for s_ in watch:
+            rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B, depth)
+            assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), f"launch {c}, stream {s_}"
+            assert o[s_].status() == d.status(s_), f"launch {c}, stream {s_}: status"
+    for x in o.values(): x.close()
+    d.close()
+
