@@ -434,7 +434,7 @@ int rebuild_launch_lists(dspi_ctx *c) {
                 for (int cls = 1; cls <= 3; cls++) for (const auto &u : used[cls]) slots[cls] += (uint64_t)__builtin_popcountll(u.second);
             }
             bool all_small = slots[1] + slots[2] + slots[3] > 0;
-            for (int cls = 1; cls <= 3; cls++) if (slots[cls] > skew_pair_limit(c->device, cls)) all_small = false;
+            for (int cls = 1; cls <= 3; cls++) if (slots[cls] > (uint64_t)skew_pair_limit(c->device, cls) * (cls == 2 ? 2u : 1u)) all_small = false;      // (class 2: see below)
             if (all_small) {
                 for (size_t i = 0; i < c->images.size(); i++) {
                     if (c->image_refs[i] == 0) continue;
@@ -447,17 +447,22 @@ int rebuild_launch_lists(dspi_ctx *c) {
                 }
                 for (int cls = 1; cls <= 3; cls++) {
                     slots[cls] = 0;
+                    size_t paired = 0;
                     for (auto &cell : cells[cls]) {
                         std::vector<Slot> &v = cell.second.v;
                         bool same = pp_on && v.size() > 1;
                         for (size_t j = 1; same && j < v.size(); j++)
                             if (memcmp(&c->image_sig[v[0].image], &c->image_sig[v[j].image], sizeof(dspi_ctx::ImageSig)) != 0) same = false;
                         cell.second.same = same;
+                        paired += same ? 1 : 0;
                         uint64_t u = 0;
                         for (const Slot &sl : v) { if (same) u |= sl.m0 | sl.m1; else slots[cls] += (uint64_t)__builtin_popcountll(sl.m0 | sl.m1); }
                         slots[cls] += (uint64_t)__builtin_popcountll(u);
                     }
-                    if (slots[cls] > skew_pair_limit(c->device, cls)) all_small = false;
+                    // Presets with output EQ and no leveller, mostly paired workgroups (every stream its own preset): the alternative is the packed
+                    // per-lane-filter kernel on an underfilled chip, and the layout wins up to twice its shared-preset limit (4 096 distinct
+                    // presets: 13.9 against 22.6 ms per 200 packets, profiles/r04_small_contexts_per_stream_leveller_off.jsonl).
+                    if (slots[cls] > (uint64_t)skew_pair_limit(c->device, cls) * ((cls == 2 && paired * 2 > cells[cls].size()) ? 2u : 1u)) all_small = false;
                 }
             }
             if (all_small) {

@@ -1126,6 +1126,36 @@ def test_i2s_slot_words_fused_into_the_chain(flavor, tiled, monkeypatch):
         plain.close(); fused.close()
 
 
+@pytest.mark.auto_layout
+def test_paired_presets_widen_the_size_rule():
+    """The library's own choice: 4 096 streams with output EQ and no leveller take the packed kernel when they share a preset (the chip is
+    filled enough) and the latency layout when every stream has its own (the alternative being the packed per-lane-filter kernel:
+    13.9 against 22.6 ms per 200 packets) — dspi_capi.cpp rebuild_launch_lists.  Sampled streams against their oracles either way."""
+    S, B, blocks, fs = 4096, 48, 4, 48000
+    blob = WL.full_chain_blob(1); blob["leveller"]["enabled"] = 0
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    watch = (0, 1, 130, 2047, 4095)
+    for distinct in (False, True):
+        d = Dspi(W.F32_FMA, S, device=0); o = {s_: Oracle(W.F32_FMA, detmath=True) for s_ in watch}
+        for x in [d] + list(o.values()):
+            x.set_rate(fs); x.set_volume(-9 * 256); assert x.load_bulk(blob) == 0
+        p_ = blob["eq"][0][1]
+        for s_ in range(S if distinct else 0):
+            reqs = [(W.REQ["SET_PREAMP"], 0, struct.pack("<f", -6.0 - 0.001 * s_)),
+                    (W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", 0, 1, int(p_["type"]), 0, float(p_["freq"]), float(p_["q"]), 1.0 + 0.001 * s_))]
+            for req, wv, pl in reqs:
+                assert d.vendor_set(req, wv, pl, stream=s_) == 0
+                if s_ in o: assert o[s_].vendor_set(req, wv, pl) == 0
+        pairs, sub, peaks = d.process_host(pcm, blocks, B)
+        plan = d.launch_plan()
+        if distinct: assert latency_plan(plan) and plan["latency_layout_paired"] == S // 4, plan
+        else: assert plan["latency_layout"] == 0 and plan["packed_shared"] == S // 128, plan
+        for s_ in watch:
+            rp, rs, rk, _ = o[s_].process(pcm[s_], blocks, B)
+            assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), (distinct, s_)
+        d.close()
+
+
 @pytest.mark.parametrize("distinct", (False, True), ids=("shared", "paired"))
 @pytest.mark.parametrize("shape,fs,B", [(1, 48000, 48), (2, 96000, 96), (3, 44100, 45), (3, 48000, 7)])
 def test_spdif_subframes_fused_into_the_chain(shape, fs, B, distinct, monkeypatch):
