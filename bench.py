@@ -24,6 +24,9 @@ What a line says (config 3):
               figure for a launch that spans more frames than a delay (8 * dly / T per frame).  The chain is on the VALU side
               of the ridge: `valu_fraction` (from the committed PMC profile of the same kernel) is the binding one.
   cpu_baseline  the reference C path on this box's host cores (a reported baseline, not the target)
+  realtime_call  (default configuration, N=1) the call as the firmware makes it: ONE packet per dspi_process(), host buffers, one stream
+              of the same preset, through the C host (dspi_host -rt): p50 / p99 us per call, every word of every call checked against
+              the oracle.  Reported beside the batched figure; never part of `value`.
 """
 from __future__ import annotations
 
@@ -310,6 +313,7 @@ def main():
     ap.add_argument("--input", choices=["mix", "noise"], default="mix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="measure only the primary variant")
+    ap.add_argument("--no-realtime", action="store_true", help="skip the one-packet-per-call measurement (dspi_host -rt, one stream) of the default configuration")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle check of the timed context (profiling runs)")
     args = ap.parse_args()
 
@@ -582,6 +586,22 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
     if primary.get("enabled_only"): out["config"]["enabled_only"] = "DSPI_OUT_ENABLED_ONLY: silent pairs and the sub are left unwritten (the firmware zero-fills them, usb_audio.c:930-933)"
     if also:
         out["also"] = also
+    # The drop-in call as the firmware makes it (usb_audio.c:1326-1332: ONE packet per call, host buffers), beside the batched figure above:
+    # dspi_host -rt (plain C over include/dspi.h) on one stream of this preset, every word of every call checked against the oracle
+    # (tools/bench_realtime.py; profiles/<round>_realtime.json holds the full table).  Reported, never part of `value`.
+    if world == 1 and flavor == 1 and args.config == "3" and not args.no_realtime:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_realtime
+            from dspi_amd.host import Dspi
+            d1 = Dspi(W.F32_FMA if args.contract == "fma" else 1, 1, device=dev.index)
+            d1.set_rate(FS); assert d1.load_bulk(w["blob"]) == 0
+            bulk = d1.collect_bulk(); d1.close()
+            r = bench_realtime.run("f32fma" if args.contract == "fma" else "f32", W.F32_FMA if args.contract == "fma" else 1, 1, FS, B, 3000, 1000, check=True, bulk=bulk)
+            out["realtime_call"] = {"what": "one packet per dspi_process(), host buffers, one stream of this preset (dspi_host -rt)", "calls": r["calls"], "p50_us": r["p50_us"], "p99_us": r["p99_us"],
+                                    "max_us": r["max_us"], "packet_us": r["packet_us"], "over_packet_time": r["over_packet_time"], "parity": r.get("parity")}
+        except BaseException as e:  # a missing dspi_host binary must not cost the line
+            out["realtime_call"] = {"what": "one packet per dspi_process()", "p50_us": None, "error": str(e)[:200]}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(flavor, FS, B, w["blob"], CH, args.contract == "fma" and flavor == 1, w["vol"], f"config {args.config}")

@@ -28,13 +28,15 @@ def preset_blob(fl, preset):
     return blob
 
 
-def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None, preset="config3"):
+def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None, preset="config3", bulk=None):
+    """bulk: the preset as REQ_GET_ALL_PARAMS bytes (bench.py passes what the PRODUCT serialised); otherwise the named preset, serialised by the oracle."""
     fl = int(flavor)
-    blob = preset_blob(fl, preset)
     pcm = WL.synth_pcm16(1, B * packets, fs, first_stream=3)[0]           # the file every stream plays (stream s is s packets behind)
-    ref = Oracle(fl); assert ref.load_bulk(blob) == 0
+    if bulk is None:
+        ref = Oracle(fl); assert ref.load_bulk(preset_blob(fl, preset)) == 0
+        bulk = ref.collect_bulk()
     with tempfile.TemporaryDirectory() as td:
-        open(os.path.join(td, "bulk.bin"), "wb").write(ref.collect_bulk())
+        open(os.path.join(td, "bulk.bin"), "wb").write(bulk)
         open(os.path.join(td, "pcm.raw"), "wb").write(np.ascontiguousarray(pcm).tobytes())
         cmd = [HOST, "-rt", "-f", flavor_name, "-s", str(S), "-r", str(fs), "-b", str(B), "-c", str(calls), "-B", os.path.join(td, "bulk.bin"),
                "-i", os.path.join(td, "pcm.raw"), "-O", os.path.join(td, "all.raw"), "-L", os.path.join(td, "lat.f64"), "-v", "-20"]
@@ -54,7 +56,7 @@ def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None, pre
             rec_b = per * 4 + C * 2
             raw = raw.reshape(calls, n_watch, rec_b)
             for wi, s in enumerate([0, S - 1][:n_watch]):
-                o = Oracle(flavor, detmath=True); assert o.set_rate(fs) == 0; o.set_volume(-20 * 256); assert o.load_bulk(ref.collect_bulk()) == 0
+                o = Oracle(flavor, detmath=True); assert o.set_rate(fs) == 0; o.set_volume(-20 * 256); assert o.load_bulk(bulk) == 0
                 idx = (np.arange(calls)[:, None] - (s % packets)) % packets          # the packet stream s plays at call c
                 data = pcm.reshape(packets, B, 2)[idx[:, 0]].reshape(calls * B, 2)
                 rp, rs, rk, _ = o.process(np.ascontiguousarray(data), calls, B)
@@ -65,7 +67,7 @@ def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None, pre
                 if not (np.array_equal(rp, gp) and np.array_equal(rs, gs) and np.array_equal(rk, gk)):
                     raise SystemExit(f"PARITY FAILURE: {flavor_name}, {S} streams, stream {s}: first differing call {int(np.argwhere((rp != gp).any(axis=(0, 2)).reshape(calls, B).any(axis=1))[0][0]) if not np.array_equal(rp, gp) else -1}")
             rec["parity"] = f"bit-exact vs the oracle over {calls} calls, streams {[0, S - 1][:n_watch]}"
-        print(json.dumps(rec), flush=True)
+        if __name__ == "__main__": print(json.dumps(rec), flush=True)
         return rec
 
 
