@@ -294,10 +294,15 @@ def test_random_numbers_one_random_structure(flavor, seed):
                 rc = d.vendor_set(req, wv, pl, stream=s_)
                 if s_ in o: assert o[s_].vendor_set(req, wv, pl) == rc
         chunk = np.ascontiguousarray(data[:, c * step:(c + 1) * step])
-        pairs, sub, peaks = d.process_host(chunk, blocks, B, depth)
+        # the second launch in a random output form: tiled words, silent outputs left unwritten (into zeroed buffers: what the firmware's
+        # zero-fill gives), the sticky clip flags along
+        kw = dict(tiled=bool(rng.random() < 0.5), enabled_only=bool(rng.random() < 0.3), clip=True) if c == 1 else {}
+        pairs, sub, peaks = d.process_host(chunk, blocks, B, depth, **kw)
+        if kw.get("tiled"): pairs, sub = d.untile(pairs, sub)
         for s_ in watch:
             rp, rs, rk, _ = o[s_].process(chunk[s_], blocks, B, depth)
-            assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), f"launch {c}, stream {s_}"
+            assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), f"launch {c}, stream {s_}, {kw}"
+            if kw.get("clip"): assert int(d.last_clip[s_]) == int.from_bytes(o[s_].status()[-2:], "little"), f"clip flags, stream {s_}"
             assert o[s_].status() == d.status(s_), f"launch {c}, stream {s_}: status"
     for x in o.values(): x.close()
     d.close()
