@@ -331,7 +331,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    backend = os.environ.get("DSPI_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("DSPI_BENCH_BACKEND") or "nccl"      # (an empty value means the default, not a backend called "")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernel is the only audio path")
     if world != args.gpus:
