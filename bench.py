@@ -19,10 +19,15 @@ What a line says (config 3):
               as built: GCC's contracted multiply-adds, include/dspi.h DSPI_FLOAT_CONTRACT_FMA), word layout `--out-layout`,
               input = SURVEY section 8d's synthetic mix (70 % noise / 10 % sweep / 10 % bursts / 5 % silence / 5 % square)
   also        the same step measured on the other variants (other contract, other layout, white-noise input), N=1 only
-  roofline    algorithmic HBM bytes / measured kernel time against 8 TB/s.  `frac` uses 104 B/frame (40 B compulsory I/O +
-              8 B per delayed output and frame: the lines live in HBM); `frac_launch_span` uses SURVEY section 8d's lower
-              figure for a launch that spans more frames than a delay (8 * dly / T per frame).  The chain is on the VALU side
-              of the ridge: `valu_fraction` (from the committed PMC profile of the same kernel) is the binding one.
+  roofline    algorithmic HBM bytes / measured kernel time against 8 TB/s.  `frac` is the STRICT figure: the bytes a launch of T frames must
+              move when the lines keep the reference's history exactly — compulsory I/O + 4 B per delayed output for the launch's first
+              min(dly, T) frames (line reads) + 4 B for its last min(line length, T) frames (line writes): 77 B/frame for config 3 at 50
+              packets per launch.  Beside it `frac_hbm_resident` (SURVEY section 8d's 104 B rule: every delayed sample written and
+              read) and `frac_launch_span` (8d's lower figure, 8 * min(dly, T) / T: 59.4 B).  `traffic_ratio` = counter bytes / the
+              strict bytes.  The chain is on the VALU side of the ridge: `valu_fraction_at_sclk` is the issue fraction at the clock the
+              socket's power limit allows; `binds` says "power" when that clock is below 0.9 x the part's maximum.
+  configs     (default run, N=1) short driver-timed runs of BASELINE configs 2, 2b and 5, each with its own roofline and its own
+              post-run oracle check; `value` stays config 3
   cpu_baseline  the reference C path on this box's host cores (a reported baseline, not the target)
   realtime_call  (default configuration, N=1) the call as the firmware makes it: ONE packet per dspi_process(), host buffers, one stream
               of the same preset, through the C host (dspi_host -rt): p50 / p99 us per call, every word of every call checked against
@@ -96,7 +101,7 @@ class PowerSampler:
         _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32), ("frequency", ctypes.c_uint64 * 33)]
 
     def __init__(self, device_index: int):
-        self.ok, self.samples, self._stop, self.cap_w = False, [], threading.Event(), None
+        self.ok, self.samples, self._stop, self.cap_w, self.max_mhz = False, [], threading.Event(), None, None
         self.dev = ctypes.c_uint32(device_index)
         try:
             self.smi = ctypes.CDLL("librocm_smi64.so")
@@ -121,6 +126,7 @@ class PowerSampler:
         mhz = None
         if self.smi.rsmi_dev_gpu_clk_freq_get(self.dev, ctypes.c_int(0), ctypes.byref(f)) == 0 and f.current < 33:
             mhz = f.frequency[f.current] / 1e6
+            if 0 < f.num_supported <= 33: self.max_mhz = max(f.frequency[i] for i in range(f.num_supported)) / 1e6      # the top of the part's clock table
         return (time.perf_counter(), pw.value / 1e6, mhz)
 
     def start(self):
@@ -138,12 +144,12 @@ class PowerSampler:
         self._stop.set(); self.th.join()
 
     def window(self, t0, t1):
-        """mean / max over the samples taken in [t0, t1] (perf_counter times); when the region is shorter than the sensor's
-        update period, the samples of its second half plus the first one after it."""
-        w = [x for x in self.samples if t0 + 0.5 * (t1 - t0) <= x[0] <= t1 + 0.02]
+        """mean / max over the samples taken in [t0, t1] (perf_counter times) plus the first one after it.  The caller has kept the device
+        under the same load for >= 0.6 s before t0 (timed_steps: untimed pre-load steps), so the whole window is the settled state."""
+        w = [x for x in self.samples if t0 <= x[0] <= t1 + 0.02]
         if not w: return None
         pw = [x[1] for x in w]; ck = [x[2] for x in w if x[2]]
-        return {"power_w": sum(pw) / len(pw), "power_w_max": max(pw), "sclk_mhz": (sum(ck) / len(ck)) if ck else None, "power_cap_w": self.cap_w, "power_samples": len(w)}
+        return {"power_w": sum(pw) / len(pw), "power_w_max": max(pw), "sclk_mhz": (sum(ck) / len(ck)) if ck else None, "power_cap_w": self.cap_w, "sclk_max_mhz": self.max_mhz, "power_samples": len(w)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -257,22 +263,29 @@ def chain_workload(name):
 
 
 def algorithmic_bytes(w, frames_per_launch):
-    """(per-frame bytes with HBM-resident delay lines, per-frame bytes by SURVEY 8d's launch-span formula)."""
+    """Per-frame HBM bytes the path must move, three ways:
+      exact    — the STRICT figure (roofline.frac): compulsory I/O + per delayed output 4 B for the launch's first min(dly, T) frames (the
+                 samples the previous launch left in the line) + 4 B for its last min(L, T) frames (the line keeps the reference's whole
+                 history of L = 4 096 / 2 048 samples: a later, longer delay reads it, usb_audio.c:1944-1951 clears nothing);
+      resident — SURVEY 8d's rule with HBM-resident lines: every delayed sample written and read, 8 B per delayed output and frame;
+      span     — SURVEY 8d's launch-span figure: 8 * min(dly, T) / T."""
     from dspi_amd import wire as W
     flavor, fs, blob = w["flavor"], w["fs"], w["blob"]
     C, N, _, P, _ = W.dims(flavor)
-    if w["channels"] == 2:                       # config 2: 4 B in + 2 x int32 out (the one live pair)
-        return 12.0, 12.0
+    if w["channels"] == 2:                       # config 2: 4 B in + 2 x int32 out (the one live pair); no delay is active
+        return dict(exact=12.0, resident=12.0, span=12.0)
     io = 4 + 4 * (N - 1) + 4                     # int16 stereo in + (N-1) int32 S/PDIF words + the Q28 sub word: 40 B float / 24 B Q28
     max_d = 4096 if flavor else 2048
-    full = span = float(io)
+    T = float(frames_per_launch)
+    full = span = exact = float(io)
     for o in range(N):
         ms = float(blob["outputs"][o]["delay_ms"]) + (128.0 / fs * 1000.0 if o == N - 1 else 0.0)
         d = min(max(int(ms * fs / 1000.0), 0), max_d)          # a delay clamped to the line length aliases to 0 samples, but the firmware
         if d > 0 and blob["outputs"][o]["enabled"]:            # still writes and re-reads the line for it (dly > 0, usb_audio.c:899-911)
             full += 8.0
-            span += 8.0 * min(1.0, d / float(frames_per_launch))
-    return full, span
+            span += 8.0 * min(1.0, d / T)
+            exact += 4.0 * min(d, T) / T + 4.0 * min(max_d, T) / T
+    return dict(exact=exact, resident=full, span=span)
 
 
 def latest_profile(kernel_key, contract, layout):
@@ -315,6 +328,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="measure only the primary variant")
     ap.add_argument("--no-realtime", action="store_true", help="skip the one-packet-per-call measurement (dspi_host -rt, one stream) of the default configuration")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle check of the timed context (profiling runs)")
+    ap.add_argument("--no-configs", action="store_true", help="default run: skip the short runs of BASELINE configs 2, 2b and 5 that follow config 3")
     args = ap.parse_args()
 
     # ---- N ranks without an external launcher: become the launcher ----
@@ -357,6 +371,26 @@ def main():
         out = bench_consumer(args, torch, dev, rank, world, dist, backend)
     else:
         out = bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_range)
+    # The other BASELINE configurations, driver-timed in the same line: short runs (a few launches after the pre-load; each context is checked
+    # against the oracle afterwards like the primary one).  `value` stays config 3.
+    if args.config == "3" and world == 1 and out is not None and not args.no_configs and not args.streams and not args.blocks_per_step:
+        out["configs"] = {}
+        for name, steps, warm in (("2", 5, 2), ("2b", 5, 2), ("5", 20, 3)):
+            a2 = argparse.Namespace(**vars(args))
+            a2.config, a2.steps, a2.warmup, a2.no_variants, a2.no_realtime, a2.no_cpu_baseline = name, steps, warm, True, True, True
+            a2.contract, a2.out_layout, a2.input = "fma", "stream", "mix"
+            try:
+                r = bench_chain(a2, torch, dev, rank, world, None, backend, Dspi, W, stream_range)
+                out["configs"][name] = {"workload": r["config"]["workload"], "dtype": r["dtype"], "steps": steps, "warmup": warm, "preload_steps": r["config"].get("preload_steps", 0),
+                                        "streams": r["config"]["streams_per_gpu"], "blocks_per_step": r["config"]["blocks_per_step"], "channels": r["config"]["channels"],
+                                        "ms_per_step": r["ms_per_step"], "frames_per_s": r["config"]["frames_per_s"], "value": r["value"], "unit": r["unit"],
+                                        "realtime_streams": r["config"]["realtime_streams"], "enabled_only": r["config"].get("enabled_only"),
+                                        "roofline": r["roofline"], "parity_checked": r.get("parity_checked", 0), "parity_streams": r.get("parity_streams"),
+                                        "parity_launches_replayed": r.get("parity_launches_replayed")}
+            except SystemExit as e:      # a parity failure of a side configuration fails the run like the primary one's
+                raise
+            except Exception as e:
+                out["configs"][name] = {"error": str(e)[:300]}
     if dist and out is not None:      # (ranks other than 0 return None)
         out["dist"] = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world_size": world,
                        "collective": "all_reduce(SUM) of the frames + all_reduce(MAX) of the elapsed time, 8 bytes each, after the timed region (dspi_amd/shard.py)"}
@@ -365,11 +399,23 @@ def main():
     if dist: dist.destroy_process_group()
 
 
-def timed_steps(args, torch, dist, backend, dev, ctx, step):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+def timed_steps(args, torch, dist, backend, dev, ctx, step, min_load_s=0.0):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
+    min_load_s: when the W warm-up steps are shorter than this, further UNTIMED steps follow them ("preload_steps") until the device has
+    been under this load for that long — socket power and shader clock need ~0.5 s to settle, and the sampler's window is the timed region."""
+    tw = time.perf_counter()
     for _ in range(args.warmup):
         step()
     ctx.sync()
+    tw = time.perf_counter() - tw
+    extra = 0
+    if min_load_s > 0.0 and tw < min_load_s:
+        per = tw / max(1, args.warmup) if args.warmup else 0.01
+        extra = min(400, int((min_load_s - tw) / max(per, 1e-4)) + 1)
+        for _ in range(extra):
+            step()
+        ctx.sync()
+    timed_steps.preload_steps = extra
     ev = HipEvents(ctx.hip_stream())
     e0, e1 = ev.new(), ev.new()
     if dist: dist.barrier()
@@ -415,24 +461,38 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
                 reqs.append((W.REQ["SET_EQ_PARAM"], 0, struct.pack("<BBBBfff", ch, 1, int(p["type"]), 0, float(p["freq"]), float(p["q"]), 1.0 + 0.0001 * s)))
         return reqs
 
-    def parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, launches, k=8):
+    def parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, launches, k=32):
         """After the timed region, outside it: K sampled streams of the TIMED context — the words, sub words and peaks its last launch left in
-        the output buffers — against the CPU oracle replaying every launch the context has run (warm-up + timed steps, the same input buffer
-        each time, state carried from launch to launch).  The checker never touches the product path; a mismatch fails the run."""
+        the output buffers — against the CPU oracle replaying every launch the context has run (warm-up + pre-load + timed steps, the same input
+        buffer each time, state carried from launch to launch).  The sample: the context's first and last streams, one stream of every input
+        class (noise, sweep, bursts, silence, square) in every third of the context, and streams spread over the workgroup rows
+        (different rows, different lanes, both halves of a lane).  The checker never touches the product path; a mismatch fails the run."""
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orclib
+        from concurrent.futures import ThreadPoolExecutor
         cand = [0, 1, 14, (S // 3) // 20 * 20 + 16, (S // 2) // 20 * 20 + 18, (2 * S // 3) // 20 * 20 + 19, S - 2, S - 1]
-        sample = sorted({min(max(c, 0), S - 1) for c in cand})[:k]
+        cand += [(S // 3) // 20 * 20 + c for c in (15, 17, 18, 19)] + [(2 * S // 3) // 20 * 20 + c for c in (3, 14, 16, 18)]
         R = ctx.tile_streams()
+        rows = max(1, (S + R - 1) // R)
+        j = 0
+        while len(set(min(max(c, 0), S - 1) for c in cand)) < min(k, S) and j < 4 * k:      # one stream in each of k rows spread over the context, lane varying
+            cand.append(((j * rows) // k) * R + (37 * j + 5) % R)
+            j += 1
+        sample = sorted({min(max(c, 0), S - 1) for c in cand})[:k]
         t0 = time.perf_counter()
-        for s in sample:
+
+        def one(s):
             o = orclib.Oracle(flavor, detmath=True, fma=fma)
             o.set_rate(FS); o.set_volume(w["vol"])
             assert o.load_bulk(w["blob"]) == 0
             for req, wv, pl in per_stream_requests(first + s): o.vendor_set(req, wv, pl)
             x = pcm[s].cpu().numpy()
             for _ in range(launches):
-                rp, rs, rk, _ = o.process(x, NB, B, 16)
+                rp, rs, rk, _ = o.process(x, NB, B, 16)      # (ctypes releases the GIL: the streams replay in parallel)
+            return rp, rs, rk, o.status()
+        with ThreadPoolExecutor(max_workers=min(len(sample), os.cpu_count() or 1)) as ex:
+            refs = list(ex.map(one, sample))
+        for s, (rp, rs, rk, rstat) in zip(sample, refs):
             if tiled:
                 gp = pairs[s // R, :, :, s % R].cpu().numpy().reshape(P, 2, frames).transpose(0, 2, 1)
                 gs = sub[s // R, :, s % R].cpu().numpy()
@@ -443,9 +503,8 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
             if not all(np.array_equal(rp[pr], gp[pr]) for pr in live) or not np.array_equal(rk, gk) or \
                not (np.array_equal(rs, gs) or (w.get("enabled_only") and int(np.abs(rs).max()) == 0)):
                 raise SystemExit(f"bench.py: PARITY FAILURE — stream {first + s} of the timed configuration differs from the oracle after {launches} launches")
-            if o.status() != ctx.status(s):
+            if rstat != ctx.status(s):
                 raise SystemExit(f"bench.py: PARITY FAILURE — status bytes of stream {first + s} differ from the oracle")
-            o.close() if hasattr(o, "close") else None
         return {"parity_checked": len(sample), "parity_streams": [first + s for s in sample], "parity_launches_replayed": launches,
                 "parity_what": "every pair word, sub word, peak of the timed context's last launch + the status bytes, bit-exact vs the CPU oracle", "parity_s": time.perf_counter() - t0}
 
@@ -476,7 +535,9 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         if smi: smi.start()
         elapsed, kernel_ms = timed_steps(args, torch, dist, backend, dev, ctx,
                                          lambda: ctx.process_device(pcm.data_ptr(), NB, B, 16, pairs.data_ptr(), sub.data_ptr(), 0 if no_peaks else peaks.data_ptr(), tiled=tiled,
-                                                                    enabled_only=bool(w.get("enabled_only")) if enabled_only is None else enabled_only))
+                                                                    enabled_only=bool(w.get("enabled_only")) if enabled_only is None else enabled_only),
+                                         min_load_s=0.6 if (smi and smi.ok) else 0.0)
+        preload = timed_steps.preload_steps
         if smi: smi.stop()
         plan = ctx.launch_plan()
         # whole job: frames of all ranks / the slowest rank's time — sum and max over ranks, 2 x 8 bytes over RCCL
@@ -486,8 +547,9 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
                  ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms, latency_layout=plan.get("latency_layout", 0) > 0)
         m["enabled_only"] = bool(w.get("enabled_only")) if enabled_only is None else enabled_only      # True: silent pairs and the sub are not zero-filled (fewer bytes than the firmware's own stores)
         if smi: m["power"] = smi.window(*timed_steps.window) if smi.ok else None
+        m["preload_steps"] = preload
         if check and rank == 0 and not args.no_parity:
-            m["parity"] = parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, args.warmup + args.steps)
+            m["parity"] = parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, args.warmup + preload + args.steps)
         ctx.close()
         del pairs, sub, peaks
         torch.cuda.empty_cache()
@@ -508,42 +570,48 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
 
     from dspi_amd.host import source_fingerprint
     SRC_SHA16 = source_fingerprint()
-    full_b, span_b = algorithmic_bytes(w, frames)
-    kernel_key = {"3": "chain3", "2": "chain2", "2b": "chain2b", "5": "chain5", "perstream": "perstream", "perstream_eq": "perstream_eq"}[args.config]
+    alg = algorithmic_bytes(w, frames)
+    kernel_key = {"3": "chain3", "2": "chain2", "2b": "chain2", "5": "chain5", "perstream": "perstream", "perstream_eq": "perstream_eq"}[args.config]
 
     def roof(m):
         per_launch_frames = S * frames
-        ach = per_launch_frames * full_b / (m["kernel_ms"] * 1e-3) / 1e9
+        gbs = lambda b: per_launch_frames * b / (m["kernel_ms"] * 1e-3) / 1e9
+        ach = gbs(alg["exact"])
         prof = latest_profile(kernel_key, m["contract"], m["out_layout"])
+        traffic = prof["hbm_bytes_per_frame"] * per_launch_frames if prof else None
         r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-             "algorithmic_bytes_per_frame": full_b, "algorithmic_bytes_per_frame_launch_span": span_b,
-             "frac_launch_span": per_launch_frames * span_b / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "frac_what": "STRICT: bytes a launch of this span must move with the lines' whole history kept (I/O + 4 B x first min(dly, T) frames read + 4 B x last min(line, T) frames written, per delayed output)",
+             "algorithmic_bytes_per_frame": alg["exact"],
+             "algorithmic_bytes_per_frame_hbm_resident": alg["resident"], "frac_hbm_resident": gbs(alg["resident"]) / HBM_PEAK_GBS,
+             "algorithmic_bytes_per_frame_launch_span": alg["span"], "frac_launch_span": gbs(alg["span"]) / HBM_PEAK_GBS,
              "kernel_ms": m["kernel_ms"], "frames_per_launch": per_launch_frames,
-             "traffic": prof["hbm_bytes_per_frame"] * per_launch_frames if prof else None, "traffic_source": prof["source"] if prof else None,
-             # the counters cannot be collected inside the timed run: they come from the committed profile of this variant, and that profile
-             # names the sources it was taken from — a different tree means the figure may describe an older kernel
+             "traffic": traffic, "traffic_source": prof["source"] if prof else None,
+             "traffic_what": "2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC profile of this kernel variant (counters cannot run inside the timed region; "
+                             "taken on the builder's box, not this one), per launch" if prof else None,
+             # that profile names the sources it was taken from — a different tree means the figure may describe an older kernel
              "traffic_stale": (prof.get("src_sha16") != SRC_SHA16) if prof else None,
-             "hbm_fraction_measured_traffic": (prof["hbm_bytes_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof else None,
+             "traffic_ratio": (traffic / (alg["exact"] * per_launch_frames)) if prof else None,
+             "hbm_fraction_measured_traffic": (gbs(prof["hbm_bytes_per_frame"]) / HBM_PEAK_GBS) if prof else None,
              "valu_fraction": (prof["valu_insts_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS) if prof and prof["valu_insts_per_frame"] else None,
              "binds": None}
-        # evidence for what binds: socket power and shader clock sampled over the timed region, the instruction
-        # issue fraction at THAT clock (a SIMD issues one wave-instruction per 4 cycles), and the bytes moved against the ~6 TB/s this
-        # memory system sustains in practice
+        # evidence for what binds: socket power and shader clock sampled over the timed region (the device under this load for >= 0.6 s before
+        # it), the instruction issue fraction at THAT clock (a SIMD issues one wave-instruction per 4 cycles), the bytes moved against 8 TB/s.
+        # The label follows the clock, not a power threshold: below 0.9 x the top of the part's clock table the socket's sustained limit is
+        # what sets the pace (time follows energy per frame: profiles/r04_power_model.md).
         pw = m.get("power")
         if pw:
-            r.update(power_w=pw["power_w"], power_w_max=pw["power_w_max"], power_cap_w=pw["power_cap_w"], sclk_mhz=pw["sclk_mhz"], power_samples=pw["power_samples"])
+            r.update(power_w=pw["power_w"], power_w_max=pw["power_w_max"], power_cap_w=pw["power_cap_w"], sclk_mhz=pw["sclk_mhz"], sclk_max_mhz=pw["sclk_max_mhz"], power_samples=pw["power_samples"])
             if pw["sclk_mhz"] and prof and prof["valu_insts_per_frame"]:
                 r["valu_fraction_at_sclk"] = prof["valu_insts_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / (1024 * pw["sclk_mhz"] * 1e6 / 4.0)
         else:
-            r.update(power_w=None, sclk_mhz=None)
-        # (tools/ablate_power.py: every variant of this kernel draws 1.31-1.37 kW of the 1.4 kW cap and the clock settles accordingly: 0.92 x the cap is "at the limit")
-        at_cap = bool(pw and pw["power_cap_w"] and pw["power_w"] >= 0.92 * pw["power_cap_w"])
+            r.update(power_w=None, sclk_mhz=None, sclk_max_mhz=None)
         issue = r.get("valu_fraction_at_sclk") or r["valu_fraction"]
         mem = r["hbm_fraction_measured_traffic"]
-        if at_cap: r["binds"] = "power: the socket sits at its sustained limit and the clock settles where that allows, so time follows energy per frame (VALU issue %s of the slots at that clock, %s of 8 TB/s moved at the L2-fabric boundary; profiles/r04_power_model.md)" % (("%.2f" % issue) if issue else "n/a", ("%.2f" % mem) if mem else "n/a")
-        elif issue and issue >= 0.60 and (not mem or issue >= mem): r["binds"] = "valu issue"
-        elif mem and mem >= 0.70: r["binds"] = "memory (bytes moved at the L2-fabric boundary)"
-        else: r["binds"] = "latency (neither issue slots nor bytes near their ceilings)"
+        if pw and pw["sclk_mhz"] and pw["sclk_max_mhz"] and pw["sclk_mhz"] < 0.9 * pw["sclk_max_mhz"]:
+            r["binds"] = "power (shader clock %.0f MHz < 0.9 x %.0f MHz under this load)" % (pw["sclk_mhz"], pw["sclk_max_mhz"])
+        elif issue and (not mem or issue >= mem): r["binds"] = "valu issue"
+        elif mem: r["binds"] = "memory (bytes moved at the L2-fabric boundary)"
+        else: r["binds"] = "unknown (no counter profile of this variant, no clock reading)"
         return r
 
     if flavor == 1:
@@ -565,7 +633,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
     roofline["kernel"] = kname
     for m in also:
         r = roof(m)
-        m["roofline_frac"], m["valu_fraction"] = r["frac"], r["valu_fraction"]
+        m["roofline_frac"], m["roofline_frac_hbm_resident"], m["valu_fraction"] = r["frac"], r["frac_hbm_resident"], r["valu_fraction"]
     out = {
         "metric": "audio samples/s (whole node), 96 kHz 11-ch 10-band PEQ; % HBM roofline",
         "value": primary["value"], "unit": "samples/s",
@@ -577,7 +645,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
                    "out_layout": "tiled [tile][output][frame][row] (DSPI_OUT_TILED)" if args.out_layout == "tiled" else "stream-major [stream][pair][frame][2] (usb_audio.c:934-940)",
                    "input": "SURVEY 8d synthetic mix (70% noise, 10% sweep, 10% bursts, 5% silence, 5% square)" if args.input == "mix" else "white noise -6 dBFS",
                    "streams_per_gpu": S, "streams_total": total if args.scaling == "strong" else total * world, "channels": CH,
-                   "blocks_per_step": NB, "frames_per_step_per_stream": frames,
+                   "blocks_per_step": NB, "frames_per_step_per_stream": frames, "preload_steps": primary.get("preload_steps", 0),
                    "frames_per_s": primary["frames_per_s"], "realtime_streams": primary["frames_per_s"] / FS, "parallelism": f"streams sharded x{world}"},
         "roofline": roofline,
     }

@@ -21,6 +21,7 @@
 #include <thread>
 #include <xmmintrin.h>
 #include <algorithm>
+#include <chrono>
 
 #include "../../include/dspi.h"
 #include "dspi_image.h"
@@ -52,6 +53,9 @@ struct dspi_ctx {
     uint32_t *d_stream_image = nullptr; size_t d_stream_image_cap = 0;   // image index per stream (per-lane parameter kernel)
     bool launch_dirty = true;
     uint32_t spdif_pos = 0;      // DSPI_OUT_SPDIF: block position of the next call's first frame
+    bool populated = false;      // DSPI_BOOT_POPULATED_FLASH: the streams are devices whose flash already holds a preset directory
+    bool audio_started = false;  // a dspi_process has run: the devices are no longer booting (dspi_load_flash_dump)
+    bool no_direct = false;      // DSPI_NO_DIRECT (development / tests, read once at dspi_create): the staged path for small host calls too
     // device
     hipStream_t hs = nullptr;
     // host-buffer dspi_process: H2D, kernels and D2H of consecutive row chunks overlap on three streams (created on first use)
@@ -702,6 +706,8 @@ int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) 
     c->sm = make_state_map(flavor);
     c->n_wg = (n_streams + (uint32_t)c->sm.row - 1) / (uint32_t)c->sm.row;
     c->fma = fma;
+    c->populated = populated;
+    c->no_direct = getenv("DSPI_NO_DIRECT") != nullptr;
     c->images.push_back(std::make_unique<Params>(flavor, fma, !populated));
     c->image_refs.push_back(n_streams);
     c->stream_image.assign(n_streams, 0);
@@ -770,7 +776,11 @@ int dspi_load_preset_slot(dspi_ctx *c, int32_t stream, const void *image, size_t
 int dspi_load_flash_dump(dspi_ctx *c, int32_t stream, const void *dump, size_t len) {
     if (!dump) return DSPI_E_INVAL;
     if (len < kFlashDumpBytes) return DSPI_E_SHORT;
-    return for_targets(c, stream, [&](Params &p) { return p.load_flash_dump(dump, len); });
+    // A context of devices with a populated flash (DSPI_BOOT_POPULATED_FLASH) that has not processed audio yet BOOTS from the dump
+    // (preset_boot_load -> apply_slot_to_live, flash_storage.c:1047-1082: no mute, no line zeroing): exact against the firmware from
+    // frame 0.  Every other context is a running device that switches to the preset the dump selects (preset_load, :794-849).
+    const bool as_boot = c->populated && !c->audio_started;
+    return for_targets(c, stream, [&](Params &p) { return p.load_flash_dump(dump, len, as_boot); });
 }
 int dspi_flash_read_directory(const void *dump, size_t len, dspi_flash_dir *out) {
     if (!dump || !out) return DSPI_E_INVAL;
@@ -1018,12 +1028,16 @@ int dspi_sync(dspi_ctx *c) {
 
 int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_blocks, uint32_t block_len, const dspi_out *out, uint32_t flags) {
     if (!c || !pcm_in || !out) return DSPI_E_INVAL;
+    // undefined flag bits are refused, not ignored: a later ABI may give them a meaning that reads further members of dspi_out
+    constexpr uint32_t kKnownFlags = DSPI_MEM_DEVICE | DSPI_OUT_TILED | DSPI_OUT_ENABLED_ONLY | DSPI_OUT_I2S_SLOTS | DSPI_OUT_SPDIF | DSPI_OUT_CLIP_FLAGS;
+    if (flags & ~kKnownFlags) return fail(c, DSPI_E_INVAL, "dspi_process: undefined flag bits");
     if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
     if ((bit_depth != 16 && bit_depth != 24) || n_blocks == 0 || block_len == 0 || block_len > DSPI_MAX_BLOCK_LEN)
         return fail(c, DSPI_E_INVAL, "bit_depth must be 16/24, 1 <= block_len <= 192, n_blocks >= 1");
     HIPCK(c, hipSetDevice(c->device));
     int rc = commit_params(c);
     if (rc) return rc;
+    c->audio_started = true;
 
     const size_t frames = (size_t)n_blocks * block_len;
     const size_t in_b = (size_t)c->n_streams * frames * (bit_depth == 24 ? 6 : 4);
@@ -1053,7 +1067,8 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     a.n_streams = c->n_streams; a.n_blocks = n_blocks; a.block_len = block_len; a.bit_depth = (uint32_t)bit_depth;
     a.tiled_out = tiled ? 1u : 0u;
     a.fma = c->fma ? 1u : 0u;
-    a.skip_silent = (flags & DSPI_OUT_ENABLED_ONLY) ? 1u : 0u;
+    // (two-pass S/PDIF: the encoder reads the WHOLE scratch chunk, so the chain must write the silent pairs' zero words there as well)
+    a.skip_silent = ((flags & DSPI_OUT_ENABLED_ONLY) && !spdif_two_pass) ? 1u : 0u;
     a.i2s_slots = (flags & DSPI_OUT_I2S_SLOTS) ? 1u : 0u;
     if (spdif) { a.spdif = spdif_two_pass ? 0u : 1u; a.spdif_pos = c->spdif_pos; }
     if (c->flavor && !tiled) {      // stream-major layout, packed kernel: the mini lines of the outputs whose rows do not reach the emit wave through their delay line (dspi_chain_pk.inc)
@@ -1069,8 +1084,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t off_pairs = up(in_b), off_sub = off_pairs + up(out->pairs ? pairs_b : 0), off_peaks = off_sub + up(out->sub ? sub_b : 0),
                  off_clip = off_peaks + up(out->peaks ? peaks_b : 0), direct_b = off_clip + up(clip_out ? (size_t)c->n_streams * 2 : 0);
-    const bool no_direct = getenv("DSPI_NO_DIRECT") != nullptr;      // development / tests: the staged path for small calls too
-    const bool direct = !dev && direct_b <= kDirectBytes && !no_direct;
+    const bool direct = !dev && direct_b <= kDirectBytes && !c->no_direct;
     if (direct && direct_b > c->direct_cap) {
         if (c->h_direct) { HIPCK(c, hipStreamSynchronize(c->hs)); (void)hipHostFree(c->h_direct); c->h_direct = nullptr; c->direct_cap = 0; }
         const size_t want = std::max<size_t>(direct_b, 64u << 10);
@@ -1108,9 +1122,12 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     int32_t *const final_pairs = a.pairs;      // where the caller's pair words / subframes end up (device side)
     uint32_t two_pass_rows = 0;
     if (spdif_two_pass) {
-        // scratch for the chain's pair words of a row chunk: at least one workgroup per CU, at most ~1 GiB
+        // scratch for the chain's pair words of a row chunk, capped by BYTES: ~1 GiB worth of rows; one workgroup per CU (256 rows) only
+        // while that stays within 2 GiB; never less than one row
         const size_t row_b = (size_t)c->sm.row * c->sm.n_pairs * frames * 8;
-        two_pass_rows = (uint32_t)std::min<size_t>(c->n_wg, std::max<size_t>(256, (size_t)(1u << 30) / row_b));
+        size_t rows = std::max<size_t>(1, ((size_t)1 << 30) / row_b);
+        if (rows < 256 && 256 * row_b <= ((size_t)2 << 30)) rows = 256;
+        two_pass_rows = (uint32_t)std::min<size_t>(c->n_wg, rows);
         if ((rc = ensure(c, c->d_spdif_words, c->d_spdif_words_cap, (size_t)two_pass_rows * row_b))) return rc;
     }
     a.img = c->d_images;
@@ -1148,7 +1165,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         for (uint32_t q0 = r0; q0 < r1; q0 += two_pass_rows) {
             const uint32_t q1 = std::min(r1, q0 + two_pass_rows);
             const size_t s0 = (size_t)q0 * row_, s1 = std::min((size_t)q1 * row_, (size_t)c->n_streams);
-            a.pairs = c->d_spdif_words - s0 * per_stream * 2;      // the kernels index by absolute stream: stream s0 lands at the scratch's start
+            a.pairs = c->d_spdif_words; a.pairs_stream0 = (uint32_t)s0;      // the kernels index by absolute stream: stream s0 lands at the scratch's start
             int r = launch_rows_1(q0, q1);
             if (r) return r;
             hipError_t e = launch_spdif(false, c->d_spdif_words, reinterpret_cast<uint32_t *>(final_pairs) + s0 * per_stream * 4, (uint32_t)(s1 - s0), (uint32_t)c->sm.n_pairs,
@@ -1172,8 +1189,14 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         if ((rc = launch_rows(0, c->n_wg))) return rc;
         if (clip_out && (rc = gather_clip(reinterpret_cast<uint16_t *>(c->d_direct + off_clip)))) return rc;
         // the launches take tens of microseconds: polling the stream answers within a microsecond of their end, a blocking wait adds a wake-up
+        // — but only for as long as such launches take: after ~300 us of polling the call falls back to the blocking wait (a hung queue, or a
+        // host running many contexts, must not pin a core)
         hipError_t q;
-        while ((q = hipStreamQuery(c->hs)) == hipErrorNotReady) {}
+        const auto spin_t0 = std::chrono::steady_clock::now();
+        uint32_t polls = 0;
+        while ((q = hipStreamQuery(c->hs)) == hipErrorNotReady) {
+            if ((++polls & 63u) == 0 && std::chrono::steady_clock::now() - spin_t0 > std::chrono::microseconds(300)) { q = hipStreamSynchronize(c->hs); break; }
+        }
         if (q != hipSuccess) return fail(c, DSPI_E_HIP, std::string("stream: ") + hipGetErrorString(q));
         if (out->pairs) memcpy(out->pairs, c->h_direct + off_pairs, pairs_b);
         if (out->sub) memcpy(out->sub, c->h_direct + off_sub, sub_b);

@@ -13,14 +13,26 @@
  *             the PCM file (wrapping); prints the latency per call (p50 / p99 / max) and the sustained rate against real time.
  *             -O all.raw: every call's words of streams 0 and streams-1 (pairs, sub, peaks per call) for the parity check of
  *             tools/bench_realtime.py; -L lat.f64: every call's latency in seconds.
+ *   dspi_host -g N [-S weak|strong] [-w warmup] ...   the node-level throughput run: ONE process, one context and one
+ *             feeder thread per GPU, streams partitioned gpu = stream / ceil(S / N) (stream_range below = dspi_amd/shard.py), buffers
+ *             resident on each device, `calls` timed dspi_process() per device between two thread barriers after `warmup` untimed ones,
+ *             then ONE collective — ncclAllReduce (RCCL over xGMI) of sum(frames) and max(seconds), 8 bytes each — and one JSON line with
+ *             bench.py's keys.  -S weak (default): -s streams PER GPU; strong: -s streams in total.  -o: device 0's first stream, last call.
+ *             -D none: no device (contexts are DSPI_DEVICE_NONE, nothing is processed): the partition, the parameter path of every
+ *             context and the reduction's host stand-in, for boxes without a GPU (tests/test_host_binary_cpu.py).
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #include "dspi.h"
+/* the HIP runtime's C API and RCCL: used by -g only (device buffers; the final all-reduce) */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 static void *slurp(const char *path, size_t *len) {
     FILE *f = fopen(path, "rb");
@@ -44,6 +56,7 @@ static int realtime(dspi_ctx *ctx, uint32_t streams, uint32_t rate, uint32_t blo
     const int pairs_n = dspi_num_pairs(ctx), ch = dspi_num_channels(ctx);
     const size_t have_packets = have_frames / block_len;
     if (!have_packets) { fprintf(stderr, "-rt needs at least one packet of input\n"); return 2; }
+    if (!calls) { fprintf(stderr, "-rt needs -c >= 1\n"); return 2; }
     int16_t *pcm = (int16_t *)malloc((size_t)streams * block_len * 4);
     dspi_out out;
     memset(&out, 0, sizeof out);
@@ -53,7 +66,10 @@ static int realtime(dspi_ctx *ctx, uint32_t streams, uint32_t rate, uint32_t blo
     double *lat = (double *)malloc(sizeof(double) * calls);
     FILE *fa = all_path ? fopen(all_path, "wb") : NULL;
     const uint32_t watch[2] = {0, streams - 1};
-    int rc;
+    int rc = 0;
+    if (all_path && !fa) { perror(all_path); rc = 2; }
+    if (!pcm || !out.pairs || !out.sub || !out.peaks || !lat) { fprintf(stderr, "-rt: out of memory\n"); rc = 2; }
+    if (rc) goto done;
     /* (the first calls allocate the context's staging buffers and build the launch lists: they are processed like every other packet — the
      *  checker must see exactly the same packets — and reported apart from the steady state) */
     for (uint32_t c = 0; c < calls; c++) {
@@ -64,7 +80,7 @@ static int realtime(dspi_ctx *ctx, uint32_t streams, uint32_t rate, uint32_t blo
         const double t0 = now();
         rc = dspi_process(ctx, pcm, 16, 1, block_len, &out, 0);
         lat[c] = now() - t0;
-        if (rc) { fprintf(stderr, "dspi_process: %d %s\n", rc, dspi_last_error(ctx)); return 1; }
+        if (rc) { fprintf(stderr, "dspi_process: %d %s\n", rc, dspi_last_error(ctx)); rc = 1; goto done; }
         if (fa)
             for (int w = 0; w < (streams > 1 ? 2 : 1); w++) {
                 const uint32_t s = watch[w];
@@ -73,8 +89,12 @@ static int realtime(dspi_ctx *ctx, uint32_t streams, uint32_t rate, uint32_t blo
                 fwrite(out.peaks + (size_t)s * ch, 2, (size_t)ch, fa);
             }
     }
-    if (fa) fclose(fa);
-    if (lat_path) { FILE *f = fopen(lat_path, "wb"); fwrite(lat, sizeof(double), calls, f); fclose(f); }
+    if (lat_path) {
+        FILE *f = fopen(lat_path, "wb");
+        if (!f) { perror(lat_path); rc = 2; goto done; }
+        fwrite(lat, sizeof(double), calls, f); fclose(f);
+    }
+    {
     double total = 0.0;
     for (uint32_t c = 0; c < calls; c++) total += lat[c];
     /* the steady state: the first 1 % of the calls (buffer allocation, first launches) are reported apart */
@@ -89,8 +109,205 @@ static int realtime(dspi_ctx *ctx, uint32_t streams, uint32_t rate, uint32_t blo
     printf("rt: %u streams x %u calls of one %u-frame packet (%.0f us of audio): p50 %.1f us  p99 %.1f us  p99.9 %.1f us  max %.1f us  (first %u calls: max %.1f us)  mean %.1f us = %.1f x real time\n",
            streams, calls, block_len, packet_s * 1e6, srt[n / 2] * 1e6, srt[(size_t)(n * 0.99)] * 1e6, srt[(size_t)(n * 0.999)] * 1e6, srt[n - 1] * 1e6, skip, first_max * 1e6,
            total / calls * 1e6, packet_s / (total / calls));
-    free(srt); free(lat); free(pcm); free(out.pairs); free(out.sub); free(out.peaks);
-    return 0;
+    free(srt);
+    }
+done:
+    if (fa) fclose(fa);
+    free(lat); free(pcm); free(out.pairs); free(out.sub); free(out.peaks);
+    return rc;
+}
+
+/* ---- -g N: the node-level run, one context + one feeder thread per GPU ---- */
+/* contiguous ranges, gpu = stream / ceil(S / n): [first, last)  (dspi_amd/shard.py:stream_range) */
+static void stream_range(uint32_t rank, uint32_t world, uint32_t total, uint32_t *first, uint32_t *last) {
+    const uint32_t per = (total + world - 1) / world;
+    const uint64_t f = (uint64_t)rank * per;
+    *first = f < total ? (uint32_t)f : total;
+    *last = (uint64_t)*first + per < total ? *first + per : total;
+}
+
+typedef struct {
+    /* in */
+    int rank, world, dry, flavor;
+    uint32_t first, last, rate, block_len, blocks, calls, warmup;
+    double vol_db;
+    const void *bulk, *slot; size_t bulk_len, slot_len;
+    const char *outp;
+    pthread_barrier_t *bar;
+    /* out */
+    int rc; char err[200];
+    double frames, seconds;
+    int channels;
+} Shard;
+
+static void *shard_main(void *arg) {
+    Shard *h = (Shard *)arg;
+    const uint32_t S = h->last - h->first;
+    const size_t frames = (size_t)h->blocks * h->block_len;
+    dspi_ctx *ctx = NULL;
+    int16_t *d_pcm = NULL; int32_t *d_pairs = NULL, *d_sub = NULL; uint16_t *d_peaks = NULL;
+    int in_barrier = 0;
+    h->frames = 0.0; h->seconds = 0.0; h->rc = 0;
+#define SHARD_FAIL(...) do { snprintf(h->err, sizeof h->err, __VA_ARGS__); h->rc = 1; goto out; } while (0)
+    if (S) {
+        int rc = dspi_create(&ctx, h->flavor, S, h->dry ? DSPI_DEVICE_NONE : h->rank);
+        if (rc) SHARD_FAIL("dspi_create on device %d: %d", h->rank, rc);
+        h->channels = dspi_num_channels(ctx);
+        if ((rc = dspi_set_sample_rate(ctx, DSPI_ALL_STREAMS, h->rate))) SHARD_FAIL("rate: %d", rc);
+        dspi_set_host_volume(ctx, DSPI_ALL_STREAMS, (int16_t)lrint(h->vol_db * 256.0));
+        if (h->bulk && (rc = dspi_load_bulk(ctx, DSPI_ALL_STREAMS, h->bulk, h->bulk_len))) SHARD_FAIL("bulk_params_apply -> %d", rc);
+        if (h->slot && (rc = dspi_load_preset_slot(ctx, DSPI_ALL_STREAMS, h->slot, h->slot_len, -1))) SHARD_FAIL("preset_load -> %d", rc);
+    }
+    if (S && !h->dry) {
+        const int pairs_n = dspi_num_pairs(ctx);
+        const size_t in_b = (size_t)S * frames * 4, pairs_b = (size_t)S * pairs_n * frames * 8, sub_b = (size_t)S * frames * 4, peaks_b = (size_t)S * h->blocks * h->channels * 2;
+        if (hipSetDevice(h->rank) != hipSuccess) SHARD_FAIL("hipSetDevice(%d)", h->rank);
+        if (hipMalloc((void **)&d_pcm, in_b) != hipSuccess || hipMalloc((void **)&d_pairs, pairs_b) != hipSuccess ||
+            hipMalloc((void **)&d_sub, sub_b) != hipSuccess || hipMalloc((void **)&d_peaks, peaks_b) != hipSuccess) SHARD_FAIL("hipMalloc of %zu MB on device %d", (in_b + pairs_b + sub_b + peaks_b) >> 20, h->rank);
+        /* xorshift32 white noise at -6 dBFS, per-stream seed by the GLOBAL stream index, uploaded in slabs of whole streams */
+        const uint32_t slab = S < 256 ? S : 256;
+        int16_t *buf = (int16_t *)malloc((size_t)slab * frames * 4);
+        if (!buf) SHARD_FAIL("out of memory");
+        for (uint32_t s0 = 0; s0 < S; s0 += slab) {
+            const uint32_t n = S - s0 < slab ? S - s0 : slab;
+            for (uint32_t s = 0; s < n; s++) {
+                uint32_t x = 0x9E3779B9u ^ ((h->first + s0 + s) * 2654435761u);
+                if (!x) x = 1;
+                int16_t *q = buf + (size_t)s * frames * 2;
+                for (size_t f = 0; f < frames * 2; f++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; q[f] = (int16_t)((int)((x >> 16) % 32769u) - 16384); }
+            }
+            if (hipMemcpy(d_pcm + (size_t)s0 * frames * 2, buf, (size_t)n * frames * 4, hipMemcpyHostToDevice) != hipSuccess) { free(buf); SHARD_FAIL("hipMemcpy H2D"); }
+        }
+        free(buf);
+        dspi_out out; memset(&out, 0, sizeof out);
+        out.pairs = d_pairs; out.sub = d_sub; out.peaks = d_peaks;
+        for (uint32_t c = 0; c < h->warmup; c++) {
+            int rc = dspi_process(ctx, d_pcm, 16, h->blocks, h->block_len, &out, DSPI_MEM_DEVICE);
+            if (rc) SHARD_FAIL("dspi_process: %d %s", rc, dspi_last_error(ctx));
+        }
+        if (dspi_sync(ctx)) SHARD_FAIL("dspi_sync: %s", dspi_last_error(ctx));
+        in_barrier = 1;
+        pthread_barrier_wait(h->bar);                 /* every device idle and warmed up: the timed region starts together */
+        const double t0 = now();
+        int rc = 0;
+        for (uint32_t c = 0; c < h->calls && !rc; c++) rc = dspi_process(ctx, d_pcm, 16, h->blocks, h->block_len, &out, DSPI_MEM_DEVICE);
+        if (!rc) rc = dspi_sync(ctx);
+        h->seconds = now() - t0;
+        pthread_barrier_wait(h->bar);
+        in_barrier = 2;
+        if (rc) SHARD_FAIL("dspi_process: %d %s", rc, dspi_last_error(ctx));
+        h->frames = (double)S * (double)frames * h->calls;
+        if (h->rank == 0 && h->outp) {                /* device 0's first stream, the last call: the test's window on the words */
+            const size_t n = (size_t)pairs_n * frames * 8;
+            void *w = malloc(n);
+            FILE *f = fopen(h->outp, "wb");
+            if (!w || !f || hipMemcpy(w, d_pairs, n, hipMemcpyDeviceToHost) != hipSuccess) { if (f) fclose(f); free(w); SHARD_FAIL("-o %s", h->outp); }
+            fwrite(w, 1, n, f); fclose(f); free(w);
+        }
+    } else if (S) {
+        h->frames = (double)S * (double)frames * h->calls;      /* dry run: what this shard WOULD have processed */
+    }
+out:
+    /* a shard that failed (or has no streams) still meets the others at the barriers */
+    if (!h->dry) for (; in_barrier < 2; in_barrier++) pthread_barrier_wait(h->bar);
+    if (d_pcm) (void)hipFree(d_pcm);
+    if (d_pairs) (void)hipFree(d_pairs);
+    if (d_sub) (void)hipFree(d_sub);
+    if (d_peaks) (void)hipFree(d_peaks);
+    if (ctx) dspi_destroy(ctx);
+    return NULL;
+#undef SHARD_FAIL
+}
+
+/* sum(frames), max(seconds) over the devices: ONE collective on 8-byte records — ncclAllReduce over the
+ * node's communicator (single process: ncclCommInitAll + a group call); -D none: the same reduction on the host */
+static int reduce_node(Shard *sh, int n, int dry, double *frames, double *seconds, const char **how) {
+    if (dry) {
+        *frames = 0.0; *seconds = 0.0;
+        for (int i = 0; i < n; i++) { *frames += sh[i].frames; if (sh[i].seconds > *seconds) *seconds = sh[i].seconds; }
+        *how = "host stand-in (no device)";
+        return 0;
+    }
+    ncclComm_t *comm = (ncclComm_t *)calloc((size_t)n, sizeof(ncclComm_t));
+    hipStream_t *st = (hipStream_t *)calloc((size_t)n, sizeof(hipStream_t));
+    double **d = (double **)calloc((size_t)n, sizeof(double *));
+    int *devs = (int *)malloc(sizeof(int) * (size_t)n);
+    int rc = 1;
+    for (int i = 0; i < n; i++) devs[i] = i;
+    if (ncclCommInitAll(comm, n, devs) != ncclSuccess) { fprintf(stderr, "ncclCommInitAll(%d) failed\n", n); goto out; }
+    for (int i = 0; i < n; i++) {
+        const double v[2] = {sh[i].frames, sh[i].seconds};
+        if (hipSetDevice(i) != hipSuccess || hipStreamCreate(&st[i]) != hipSuccess || hipMalloc((void **)&d[i], 32) != hipSuccess ||
+            hipMemcpy(d[i], v, 16, hipMemcpyHostToDevice) != hipSuccess) { fprintf(stderr, "reduce: device %d\n", i); goto out; }
+    }
+    ncclGroupStart();
+    for (int i = 0; i < n; i++) ncclAllReduce(d[i], d[i] + 2, 1, ncclDouble, ncclSum, comm[i], st[i]);
+    for (int i = 0; i < n; i++) ncclAllReduce(d[i] + 1, d[i] + 3, 1, ncclDouble, ncclMax, comm[i], st[i]);
+    if (ncclGroupEnd() != ncclSuccess) { fprintf(stderr, "ncclAllReduce failed\n"); goto out; }
+    for (int i = 0; i < n; i++) { (void)hipSetDevice(i); if (hipStreamSynchronize(st[i]) != hipSuccess) goto out; }
+    {
+        double r[2];
+        (void)hipSetDevice(0);
+        if (hipMemcpy(r, d[0] + 2, 16, hipMemcpyDeviceToHost) != hipSuccess) goto out;
+        *frames = r[0]; *seconds = r[1];
+    }
+    *how = "rccl: ncclAllReduce(sum frames) + ncclAllReduce(max seconds), 8 bytes each, one process, ncclCommInitAll";
+    rc = 0;
+out:
+    for (int i = 0; i < n; i++) {
+        (void)hipSetDevice(i);
+        if (d[i]) (void)hipFree(d[i]);
+        if (st[i]) (void)hipStreamDestroy(st[i]);
+        if (comm[i]) ncclCommDestroy(comm[i]);
+    }
+    free(comm); free(st); free(d); free(devs);
+    return rc;
+}
+
+static int node_run(int n_gpus, int strong, int dry, int flavor, uint32_t streams, uint32_t rate, uint32_t block_len, uint32_t blocks, uint32_t calls,
+                    uint32_t warmup, double vol_db, const char *bulk, const char *slot, const char *outp) {
+    if (n_gpus < 1 || n_gpus > 64 || !calls || !streams) { fprintf(stderr, "-g: 1..64 devices, -c >= 1, -s >= 1\n"); return 2; }
+    if (!dry) {
+        int have = 0;
+        if (hipGetDeviceCount(&have) != hipSuccess || have < n_gpus) { fprintf(stderr, "-g %d: %d device(s) visible\n", n_gpus, have); return 1; }
+    }
+    size_t bulk_len = 0, slot_len = 0;
+    void *bulk_b = bulk ? slurp(bulk, &bulk_len) : NULL, *slot_b = slot ? slurp(slot, &slot_len) : NULL;
+    const uint32_t total = strong ? streams : streams * (uint32_t)n_gpus;
+    Shard *sh = (Shard *)calloc((size_t)n_gpus, sizeof(Shard));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_gpus, sizeof(pthread_t));
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)n_gpus);
+    for (int i = 0; i < n_gpus; i++) {
+        Shard *h = &sh[i];
+        h->rank = i; h->world = n_gpus; h->dry = dry; h->flavor = flavor;
+        stream_range((uint32_t)i, (uint32_t)n_gpus, total, &h->first, &h->last);
+        h->rate = rate; h->block_len = block_len; h->blocks = blocks; h->calls = calls; h->warmup = warmup; h->vol_db = vol_db;
+        h->bulk = bulk_b; h->bulk_len = bulk_len; h->slot = slot_b; h->slot_len = slot_len; h->outp = outp; h->bar = &bar;
+        pthread_create(&th[i], NULL, shard_main, h);
+    }
+    int rc = 0, channels = 0;
+    for (int i = 0; i < n_gpus; i++) {
+        pthread_join(th[i], NULL);
+        if (sh[i].rc) { fprintf(stderr, "device %d: %s\n", i, sh[i].err); rc = 1; }
+        if (sh[i].channels) channels = sh[i].channels;
+    }
+    pthread_barrier_destroy(&bar);
+    double frames = 0.0, seconds = 0.0; const char *how = "";
+    if (!rc) rc = reduce_node(sh, n_gpus, dry, &frames, &seconds, &how);
+    if (!rc) {
+        const double fps = seconds > 0.0 ? frames / seconds : 0.0;
+        printf("{\"metric\": \"audio samples/s (whole node)\", \"value\": %.6e, \"unit\": \"samples/s\", \"n_gpus\": %d, \"steps\": %u, \"warmup\": %u, "
+               "\"ms_per_step\": %.6f, \"higher_is_better\": true, \"scaling\": \"%s\", \"vs_baseline\": null, \"dtype\": \"%s\", \"data\": \"synthetic\", "
+               "\"config\": {\"workload\": \"dspi_host -g: %u streams in total, %u Hz, %u packets of %u frames per call\", \"streams_total\": %u, \"channels\": %d, "
+               "\"frames\": %.0f, \"seconds\": %.6f, \"frames_per_s\": %.6e, \"realtime_streams\": %.1f, \"parallelism\": \"one process, one context + feeder thread per GPU\", \"shards\": [",
+               fps * channels, n_gpus, calls, warmup, seconds / calls * 1e3, strong ? "strong" : "weak", (flavor & 0xff) ? "f32" : "int32 (Q28)",
+               total, rate, blocks, block_len, total, channels, frames, seconds, fps, fps / rate);
+        for (int i = 0; i < n_gpus; i++) printf("%s[%u, %u]", i ? ", " : "", sh[i].first, sh[i].last);
+        printf("]}, \"dist\": {\"backend\": \"%s\", \"world_size\": %d}, \"dry_run\": %s}\n", how, n_gpus, dry ? "true" : "false");
+    }
+    free(sh); free(th); free(bulk_b); free(slot_b);
+    return rc;
 }
 
 int main(int argc, char **argv) {
@@ -98,7 +315,8 @@ int main(int argc, char **argv) {
     uint32_t streams = 4096, rate = 48000, block_len = 48, blocks = 100, calls = 10;
     const char *bulk = NULL, *slot = NULL, *in = NULL, *outp = NULL, *allp = NULL, *latp = NULL;
     double vol_db = 0.0;
-    int rt = 0;
+    int rt = 0, n_gpus = 0, strong = 0, dry = 0;
+    uint32_t warmup = 2;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i], *v = (i + 1 < argc) ? argv[i + 1] : NULL;
         if (!strcmp(a, "-f") && v) {      /* f32fma: the float flavour with the firmware build's fused multiply-adds (dspi.h) */
@@ -115,10 +333,16 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "-o") && v) { outp = v; i++; }
         else if (!strcmp(a, "-v") && v) { vol_db = atof(v); i++; }
         else if (!strcmp(a, "-rt")) rt = 1;
+        else if (!strcmp(a, "-g") && v) { n_gpus = atoi(v); i++; }
+        else if (!strcmp(a, "-S") && v) { strong = !strcmp(v, "strong"); i++; }
+        else if (!strcmp(a, "-w") && v) { warmup = (uint32_t)atoi(v); i++; }
+        else if (!strcmp(a, "-D") && v) { dry = !strcmp(v, "none"); i++; }
         else if (!strcmp(a, "-O") && v) { allp = v; i++; }
         else if (!strcmp(a, "-L") && v) { latp = v; i++; }
-        else { fprintf(stderr, "usage: %s [-f q28|f32|f32fma] [-s streams] [-r rate] [-b block_len] [-n blocks] [-c calls] [-B bulk.bin|-P slot.bin] [-i pcm.raw] [-o pairs.raw] [-v vol_db]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [-f q28|f32|f32fma] [-s streams] [-r rate] [-b block_len] [-n blocks] [-c calls] [-B bulk.bin|-P slot.bin] [-i pcm.raw] [-o pairs.raw] [-v vol_db] [-rt] [-g gpus [-S weak|strong] [-w warmup] [-D none]]\n", argv[0]); return 2; }
     }
+    if (n_gpus > 0) return node_run(n_gpus, strong, dry, flavor, streams, rate, block_len, blocks, calls, warmup, vol_db, bulk, slot, outp);
+    if (dry) { fprintf(stderr, "-D none goes with -g\n"); return 2; }
     dspi_ctx *ctx = NULL;
     int rc = dspi_create(&ctx, flavor, streams, 0);
     if (rc) { fprintf(stderr, "dspi_create failed (%d): the HIP library needs a GPU\n", rc); return 1; }
@@ -160,6 +384,7 @@ int main(int argc, char **argv) {
     }
     const int pairs_n = dspi_num_pairs(ctx), ch = dspi_num_channels(ctx);
     dspi_out out;
+    memset(&out, 0, sizeof out);
     out.pairs = (int32_t *)malloc((size_t)streams * pairs_n * frames * 8);
     out.sub = (int32_t *)malloc((size_t)streams * frames * 4);
     out.peaks = (uint16_t *)malloc((size_t)streams * blocks * ch * 2);
@@ -178,7 +403,11 @@ int main(int argc, char **argv) {
     printf("stream 0 status (%d bytes): peaks", n);
     for (int i = 0; i < ch; i++) printf(" %u", st[i * 2] | (st[i * 2 + 1] << 8));
     printf(" clip 0x%04x\n", st[ch * 2 + 2] | (st[ch * 2 + 3] << 8));
-    if (outp) { FILE *f = fopen(outp, "wb"); fwrite(out.pairs, 8, (size_t)pairs_n * frames, f); fclose(f); }
+    if (outp) {
+        FILE *f = fopen(outp, "wb");
+        if (!f) { perror(outp); return 2; }
+        fwrite(out.pairs, 8, (size_t)pairs_n * frames, f); fclose(f);
+    }
     dspi_destroy(ctx);
     return 0;
 }

@@ -24,6 +24,8 @@ struct KArgs {
     uint32_t tiled_out;      // DSPI_OUT_TILED: pairs = [tile][output][frames][row], sub = [tile][frames][row] (row = StateMap::row)
     uint32_t *xwords;        // packed float kernel, stream-major output: mini lines [n_wg][3][kMaxOut][kChunk][128] words — the rows of outputs that do not reach their pair's waves through the delay line (dspi_chain_pk.inc output_item_pk)
     const float *vals;       // packed float kernel, per-lane values: value tiles [n_wg][kPvTileFloats] (dspi_image.h) or null
+    uint32_t pairs_stream0;  // stream-major `pairs` starts at this stream (0: the caller's whole buffer; the two-pass S/PDIF path hands the kernels a scratch buffer that
+                             // holds a chunk of rows)
     uint32_t skip_silent;    // DSPI_OUT_ENABLED_ONLY: sample words of silent outputs (a disabled S/PDIF pair, the sub while it is off) need not be stored
     uint32_t i2s_slots;      // DSPI_OUT_I2S_SLOTS: pairs whose slot is an I2S slot (DevImage::i2s_pairs) carry left-justified I2S words (word << 8)
     uint32_t spdif;          // DSPI_OUT_SPDIF (latency layout only): `pairs` takes IEC 60958 subframes, uint32 [stream][pair][frame][4]

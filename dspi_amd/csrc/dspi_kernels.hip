@@ -687,7 +687,7 @@ __device__ __forceinline__ void output_item_f32(const KArgs &a, const DevImage *
 #pragma unroll
                 for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[(size_t)i * ROW] = wv[i]; }
             } else if (a.pairs && active) {
-                int32_t *dst = a.pairs + (((size_t)stream * sm.n_pairs + pair) * F + frame0) * 2;
+                int32_t *dst = a.pairs + (((size_t)(stream - a.pairs_stream0) * sm.n_pairs + pair) * F + frame0) * 2;
                 if (side == 1 && partner_here) {
                     if (!TAIL) {
 #pragma unroll
@@ -1126,7 +1126,7 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const S
 #pragma unroll
                 for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[(size_t)i * ROW] = wv[i]; }
             } else if (a.pairs) {
-                int32_t *dst = a.pairs + (((size_t)stream * sm.n_pairs + pair) * F + frame0) * 2;
+                int32_t *dst = a.pairs + (((size_t)(stream - a.pairs_stream0) * sm.n_pairs + pair) * F + frame0) * 2;
                 if (side == 1 && partner_here) {
 #pragma unroll
                     for (int i = 0; i < T; ++i) { if (TAIL && i >= n) break; dst[i * 2] = held[i]; dst[i * 2 + 1] = wv[i]; }

@@ -177,10 +177,11 @@ Params::Params(int fl, bool fma, bool first_boot_) {
 
 int Params::slot_size() const { return flavor ? 2864 : 1840; }
 
-// Power-on sequence on a blank flash: global initialisers (usb_audio.c:47-214), usb_sound_card_init
-// (:3251-3270, :3382-3385), core0_init (main.c:645-696) and the first main-loop pass, which runs the
-// rate change that _audio_reconfigure() queued for audio_state.freq = 44100.
-void Params::boot() {
+// Power-on sequence: global initialisers (usb_audio.c:47-214), usb_sound_card_init (:3251-3270, :3382-3385), core0_init
+// (main.c:645-696) with preset_boot_load on `flash` (a 48 KB preset area; nullptr: an erased one, or — !first_boot — one that holds a
+// directory and no selected preset), and the first main-loop pass, which runs the rate change that _audio_reconfigure() queued for
+// audio_state.freq = 44100.  Returns preset_boot_load's selection (flash_select's codes; 48 without a flash image).
+int Params::boot(const void *flash) {
     FtzScope ftz;
     freq = 44100;
     master_db = kMasterDefaultDb; master_linear = 0.1f; master_q15 = 3277;
@@ -196,8 +197,24 @@ void Params::boot() {
     apply_factory_defaults();
     recalc_all_filters(48000.0f);
     set_volume(0);
+    // core0_init: preset_boot_load — the slot goes into the live parameters and nothing else happens (apply_slot_to_live,
+    // flash_storage.c:1047-1082: no mute, the delay lines are not touched); then the filters and delays of the loaded (or default) preset
+    int sel = 48;
+    bool boot_wrote = false;      // a boot that WRITES the flash arms the mute like the first boot: no directory (legacy migration or a fresh
+                                  // directory, flash_storage.c:1084-1104), or a v1 directory, which dir_load_cache persists as v2 (:391-414)
+    if (flash) {
+        sel = flash_select(flash, true);
+        FlashDirectory fd;
+        boot_wrote = !parse_flash_directory(flash, kFlashDumpBytes, fd) || fd.version == 1;
+    }
+    recalc_all_filters(48000.0f);
     update_delay_samples(48000.0f);
+    // slots the preset saved as I2S are converted by process_type_switches before Core 1 starts (main.c:651-684), and that arms the
+    // pipeline mute like every type switch (prepare_pipeline_reset(PRESET_MUTE_SAMPLES), :279)
+    bool boot_i2s = false;
+    for (int i = 0; i < n_pairs; i++) boot_i2s |= output_types[i] != 0;
     loudness_recompute(48000.0f); loud_pending = false;
+    if (loudness_enabled && loud_table_valid) set_volume(volume);      // main.c:688-691
     leveller_design(48000.0f); lev_pending = false; lev_reset_pending = false;
     leveller_bypassed = !lev_cfg.enabled;
     transition_core1();
@@ -208,8 +225,10 @@ void Params::boot() {
     // and every flash_write_sector re-arms the preset mute for flash_mute_hold_samples() = max(10 ms, 512) samples at the
     // power-on rate of 44.1 kHz (:272-276, :347-348): a new device starts with 512 muted samples and the fade-in.  A device whose
     // flash already holds a directory writes nothing at boot and does not mute (DSPI_BOOT_POPULATED_FLASH, include/dspi.h).
-    if (first_boot) pipeline_mute(512);
+    if (first_boot || boot_wrote) pipeline_mute(512);
+    if (boot_i2s) pipeline_mute(kPresetMuteSamples);      // (after the directory write in program order: the last writer's count stands)
     dirty = true;
+    return sel;
 }
 
 // ============================================================================================
@@ -763,11 +782,9 @@ int Params::collect_bulk(void *blob, size_t cap) const {   // bulk_params_collec
 }
 
 // preset_load path (main.c:926-976, flash_storage.c:750-759, :794-849) + apply_slot_to_live (:597-742)
-int Params::load_slot(const void *image, size_t len, int expect_slot) {
-    if (len < (size_t)slot_size()) return 3;    // PRESET_ERR_CRC
-    FtzScope ftz;
-    pipeline_mute(kPresetMuteSamples);
-    uint8_t old_types[4]; memcpy(old_types, output_types, 4);
+// validate_slot + apply_slot_to_live + apply_master_volume_from_mode (flash_storage.c:750-759, :597-742): a slot image into the live
+// parameters, nothing else — what preset_load (load_slot below) and the boot path (boot_select) share.  false: bad magic / index / CRC.
+bool Params::slot_to_live(const void *image, int expect_slot) {
     SlotCursor c(image);
     uint32_t magic = c.get<uint32_t>();
     uint16_t version = c.get<uint16_t>();
@@ -775,7 +792,7 @@ int Params::load_slot(const void *image, size_t len, int expect_slot) {
     uint32_t crc = c.get<uint32_t>();
     bool ok = magic == kSlotMagic && (expect_slot < 0 || slot_index == (uint16_t)expect_slot) &&
               crc32_edb88320((const uint8_t *)image + 12, (size_t)slot_size() - 12) == crc;
-    if (!ok) { ops.mute_start = 0; ops.mute_cancel = 1; return 3; }    // preset_loading = false (:806)
+    if (!ok) return false;
 
     for (int ch = 0; ch < n_ch; ch++) for (int b = 0; b < kStoredBands; b++) recipes[ch][b] = c.get<Recipe>();
     float legacy_preamp = c.get<float>();
@@ -848,6 +865,15 @@ int Params::load_slot(const void *image, size_t len, int expect_slot) {
         preamp_mul[i] = f2i_sat(lin * (float)(1 << 28)); preamp_linear[i] = lin;
     }
     apply_master_from_mode(true, version, slot_master);
+    return true;
+}
+
+int Params::load_slot(const void *image, size_t len, int expect_slot) {     // preset_load (flash_storage.c:794-849) under main.c:926-976
+    if (len < (size_t)slot_size()) return 3;    // PRESET_ERR_CRC
+    FtzScope ftz;
+    pipeline_mute(kPresetMuteSamples);
+    uint8_t old_types[4]; memcpy(old_types, output_types, 4);
+    if (!slot_to_live(image, expect_slot)) { ops.mute_start = 0; ops.mute_cancel = 1; return 3; }    // preset_loading = false (:806)
 
     float fs = (float)freq;
     recalc_all_filters(fs); update_delay_samples(fs);
@@ -900,21 +926,22 @@ bool parse_flash_directory(const void *dump, size_t len, FlashDirectory &d) {
     return true;
 }
 
-// Return: 0..9 slot loaded | 16+slot: that slot was selected but is empty or corrupt -> factory defaults |
-//         32: no directory, legacy sector migrated into slot 0 and loaded | 48: nothing usable -> factory defaults | -4 short dump
-// The SELECTION is preset_boot_load's (flash_storage.c:1047-1105); the APPLICATION is preset_load's (:794-849: mute,
-// delay lines zeroed), because a context is a running device, not one that is booting.
-int Params::load_flash_dump(const void *dump, size_t len) {
-    if (!dump || len < kFlashDumpBytes) return -4;
+// preset_boot_load's SELECTION on a 48 KB flash image (flash_storage.c:1047-1105).  Return: 0..9 slot loaded | 16+slot: that slot was
+// selected but is empty or corrupt -> factory defaults | 32: no directory, legacy sector migrated into slot 0 and loaded | 48: nothing
+// usable -> factory defaults.  `booting`: the APPLICATION is the boot path's too (apply_slot_to_live / apply_factory_defaults and nothing
+// else, :1066-1076); otherwise it is preset_load's (:794-849: mute, delay lines zeroed) — a running device switching to that preset.
+int Params::flash_select(const void *dump, bool booting) {
     const uint8_t *p = static_cast<const uint8_t *>(dump);
+    auto apply = [&](const void *image, int slot) { return booting ? (slot_to_live(image, slot) ? 0 : 3) : load_slot(image, (size_t)slot_size(), slot); };
+    auto defaults = [&]() { if (booting) apply_factory_defaults(); else factory_reset(); };
     FlashDirectory d;
-    if (parse_flash_directory(dump, len, d)) {
+    if (parse_flash_directory(dump, kFlashDumpBytes, d)) {
         uint8_t target = d.startup_mode == 1 ? d.last_active_slot : d.default_slot;      // PRESET_STARTUP_LAST_ACTIVE
         if (target >= 10) { target = d.default_slot; if (target >= 10) target = 0; }
         dir_master_volume_mode = d.master_volume_mode; dir_master_volume_db = d.master_volume_db; dir_include_pins = d.include_pins;
         if ((d.slot_occupied >> target) & 1u)
-            if (load_slot(p + (1 + (size_t)target) * kSector, (size_t)slot_size(), target) == 0) return target;
-        factory_reset();
+            if (apply(p + (1 + (size_t)target) * kSector, target) == 0) return target;
+        defaults();
         return 16 + target;
     }
     // no directory: migrate_legacy (flash_storage.c:997-1045) — the legacy sector's data section has the slot's layout
@@ -930,13 +957,32 @@ int Params::load_flash_dump(const void *dump, size_t len) {
         const uint32_t crc = crc32_edb88320(&slot[12], (size_t)slot_size() - 12);
         memcpy(&slot[8], &crc, 4);
         dir_include_pins = 0;                       // "Legacy migration: don't override pins" (:1091)
-        const int rc = load_slot(slot.data(), slot.size(), 0);
+        const int rc = apply(slot.data(), 0);
         dir_include_pins = 1;
         if (rc == 0) return 32;
     }
     dir_include_pins = 1;                           // dir_ensure (:440-457)
-    factory_reset();
+    defaults();
     return 48;
+}
+
+// `as_boot`: the stream is a device with a populated flash that has not played anything yet (dspi_capi.cpp decides) — the dump is the
+// flash it BOOTS from: the power-on sequence runs again over it (no mute, no line zeroing: preset_boot_load, flash_storage.c:1047-1082),
+// and what the host has set since power-on in the firmware's own way (sample rate, UAC1 volume and mute) is set again afterwards.
+int Params::load_flash_dump(const void *dump, size_t len, bool as_boot) {
+    if (!dump || len < kFlashDumpBytes) return -4;
+    if (!as_boot) { FtzScope ftz; return flash_select(dump, false); }
+    const uint32_t hz = freq; const int16_t v = volume; const bool m = mute;
+    const int fl = flavor; const bool fma = fma_contract;
+    memset((void *)this, 0, sizeof(*this));
+    first_boot = false; flavor = fl; fma_contract = fma;
+    StateMap sm = make_state_map(fl);
+    n_ch = sm.n_ch; n_out = sm.n_out; n_pairs = sm.n_pairs; max_delay = sm.max_delay;
+    n_pins = fl ? 5 : 3;
+    const int sel = boot(dump);
+    if (hz != freq) set_rate(hz);
+    set_volume(v); set_mute(m);
+    return sel;
 }
 
 int Params::save_slot(void *image, size_t cap, int slot_index) const {   // collect_live_state, flash_storage.c:464-552

@@ -54,13 +54,15 @@ public:
     explicit Params(int flavor, bool fma_contract = false, bool first_boot = true);
 
     // ---- operations (each cites the reference entry point in dspi_params.cpp) ----
-    void boot();
+    int boot(const void *flash = nullptr);      // the power-on sequence (over a 48 KB preset area, or none)
     void factory_reset();
     int load_bulk(const void *blob, size_t len);
     int collect_bulk(void *blob, size_t cap) const;
     int load_slot(const void *image, size_t len, int expect_slot);
+    bool slot_to_live(const void *image, int expect_slot);      // apply_slot_to_live + apply_master_volume_from_mode, nothing else
+    int flash_select(const void *dump, bool booting);           // preset_boot_load's selection; the application by `booting`
     int save_slot(void *image, size_t cap, int slot_index) const;
-    int load_flash_dump(const void *dump, size_t len);      // preset_boot_load's selection on a 48 KB flash image
+    int load_flash_dump(const void *dump, size_t len, bool as_boot = false);      // preset_boot_load on a 48 KB flash image: a running device switching to the selected preset, or (as_boot) the device booting from it
     int vendor_set(uint8_t req, uint16_t wValue, const void *payload, uint16_t len);
     int vendor_get(uint8_t req, uint16_t wValue, void *buf, uint16_t cap, const uint16_t *peaks, uint16_t *clip_flags);
     void set_volume(int16_t v);

@@ -23,8 +23,22 @@
  *
  * Numerics: DSPI_FLAVOR_RP2040_Q28 is bit-exact integer arithmetic; DSPI_FLAVOR_RP2350_F32
  * is IEEE binary32 with flush-to-zero, either with no contraction or (DSPI_FLOAT_CONTRACT_FMA) with
- * exactly the fused multiply-adds GCC gives the firmware.  All match oracle/ bit-for-bit
- * (tests/), the leveller's per-block log10f/powf being defined by include/dspi_detmath.h.
+ * exactly the fused multiply-adds GCC gives the firmware.  All match oracle/ bit-for-bit (tests/).
+ * ONE boundary is defined by this repository rather than by the reference: the leveller calls
+ * log10f once and powf twice per packet (leveller.c:178, :200, :206), the firmware links them from
+ * an unpinned newlib / pico-float, and no libm agrees with another in the last bit.  Both the
+ * product and the oracle therefore compute them with include/dspi_detmath.h (binary64 add / mul /
+ * div only), and the reference build used for pinning is compiled with oracle/ref_math_hook.h
+ * (-include), which routes leveller.c's log10f / powf to the same header — the reference build is
+ * MODIFIED at exactly this boundary and nowhere else.  Measured distance (tests/test_detmath.py):
+ * <= 1 ulp from the correctly rounded result (under 1 in 10^4 arguments differ at all), <= 2 ulp
+ * from glibc's log10f / powf over the leveller's argument ranges; one golden vector crosses the
+ * boundary: tests/golden/f32_full_96k_libm.npz (the reference with glibc's own libm, BASELINE
+ * config 3's preset) is reproduced word for word by the oracle and by the GPU.
+ * The float-to-int casts saturate as on both MCUs (vcvt.s32.f32 / the RP2040 bootrom's
+ * float2int_z); an x86 build of the same C gives INT_MIN instead — for Q28 the one place this
+ * shows in normal operation is the limiter quotient (leveller.c:376), where "bit-exact" rests on
+ * that restated rule, not on executed reference code.
  *
  * Threading: a context is single-threaded.  Parameter calls take effect at the next
  * dspi_process() (= at a packet boundary, as in the firmware's main loop, main.c:826-894).
@@ -64,12 +78,15 @@ extern "C" {
  * preset mute for flash_mute_hold_samples() = max(10 ms, 512) samples (:272-276, :347-348) — so a new context starts with 512 muted
  * samples and the fade-in (5 to 12 ms of silence / ramp at the start of the first packets).  With DSPI_BOOT_POPULATED_FLASH the streams
  * are devices whose flash already holds a directory: nothing is written at boot, audio starts unmuted; load the preset such a device
- * would have booted with dspi_load_flash_dump / dspi_load_preset_slot.  LIMITATION: both apply the preset the way REQ_PRESET_LOAD does
- * on a RUNNING device (preset_load, flash_storage.c:794-849: the max(10 ms, 512)-sample mute is armed, the delay lines are zeroed),
- * whereas the firmware's boot path (preset_boot_load -> apply_slot_to_live, :1047-1082) writes no flash and arms no mute: a device
- * that boots a NON-default preset from a populated flash is therefore modelled from the end of that mute on, not from frame 0
- * (tests/test_gpu_parity.py::test_flash_dump_boots_device_context compares with the firmware build after the mutes have run out;
- * the factory-default preset, which needs no load, is exact from frame 0: ::test_boot_from_populated_flash_has_no_first_boot_mute). */
+ * would have booted with dspi_load_flash_dump BEFORE the first dspi_process: on such a context that call IS the boot — the power-on
+ * sequence runs again over the dump (preset_boot_load -> apply_slot_to_live, flash_storage.c:1047-1082: the selected slot goes into
+ * the live parameters, no mute is armed, no line is zeroed; a boot that itself writes the flash — no directory, a legacy sector to
+ * migrate, a v1 directory to convert — arms the 512-sample mute like a first boot; slots saved as I2S arm the type-switch mute,
+ * main.c:651-684), and the sample rate, UAC1 volume and mute set since dspi_create are set again after it.  Exact against the firmware
+ * build booted from the same flash FROM FRAME 0 (tests/test_gpu_parity.py::test_flash_dump_boots_device_context,
+ * tests/test_oracle_vs_fw.py::test_boot_from_flash_dumps).  Once a context has processed audio — and on every context without the
+ * flag — dspi_load_flash_dump is a running device switching to the preset the dump selects (preset_load, flash_storage.c:794-849:
+ * max(10 ms, 512)-sample mute, delay lines zeroed), exactly like dspi_load_preset_slot. */
 #define DSPI_BOOT_POPULATED_FLASH 0x200
 
 #define DSPI_ALL_STREAMS (-1)
@@ -87,7 +104,8 @@ extern "C" {
 /* dspi_load_bulk returns the firmware's own codes: -1 version, -2 platform, -3 channel counts, -4 length */
 /* dspi_load_preset_slot returns PRESET_OK (0) or PRESET_ERR_CRC (3)  (config.h:262-266) */
 
-/* dspi_process flags */
+/* dspi_process flags.  Bits not defined here are refused (DSPI_E_INVAL), never ignored: a later ABI may give a bit a meaning that
+ * reads further members of dspi_out (as DSPI_OUT_CLIP_FLAGS did in ABI 7). */
 #define DSPI_MEM_DEVICE 0x1u       /* pcm_in and every pointer in dspi_out are device pointers (zero-copy) */
 #define DSPI_OUT_TILED 0x2u        /* pairs / sub use the device-native tiled layout described at dspi_out */
 #define DSPI_OUT_I2S_SLOTS 0x8u    /* pairs whose slot is an I2S slot in the stream's own parameters (output_types[], REQ_SET_OUTPUT_TYPE 0xC0) are written as
@@ -109,7 +127,11 @@ extern "C" {
                                     * runs the EQ worker — so the library may leave those parts of pairs / sub unwritten instead of storing
                                     * zeros (36 of the 40 bytes per frame for a preset with one live pair).  Peaks, status and every live
                                     * output are unaffected.  Honoured by the float chain's latency layout; the other kernels write the zeros
-                                    * (host buffers: the silent parts come back as zeros either way). */
+                                    * (host buffers: the silent parts come back as zeros either way).  With DSPI_OUT_SPDIF: where the library
+                                    * serves the call in two passes (any lane off the latency layout) the silent pairs carry the subframes of
+                                    * SILENCE, exactly as without this flag; where the latency layout's output waves encode the subframes
+                                    * themselves the silent pairs are left unwritten (host buffers: zero words, which are not valid subframes —
+                                    * do not shift them out). */
 #define DSPI_OUT_CLIP_FLAGS 0x20u  /* the dspi_out passed has the ABI-7 member clip_flags (below) and the library may write through it */
 
 typedef struct dspi_ctx dspi_ctx;
@@ -180,8 +202,9 @@ typedef struct dspi_flash_dir {
 /* dir_load_cache: flash_storage.c:370-417 (no context needed) */
 int dspi_flash_read_directory(const void *dump, size_t len, dspi_flash_dir *out);
 /* Picks the startup preset the way preset_boot_load does (flash_storage.c:1047-1105: startup mode, occupancy, slot
- * validation, legacy-sector migration :997-1045) and applies it the way REQ_PRESET_LOAD does (a context is a running
- * device).  Returns 0..9 = that slot was loaded; 16+n = slot n was selected but is empty or corrupt, factory defaults
+ * validation, legacy-sector migration :997-1045).  On a DSPI_BOOT_POPULATED_FLASH context that has not processed audio yet
+ * the call is the device's BOOT from that flash (see the flag: no mute, no line zeroing, exact from frame 0); on every
+ * other context the preset is applied the way REQ_PRESET_LOAD does on a running device.  Returns 0..9 = that slot was loaded; 16+n = slot n was selected but is empty or corrupt, factory defaults
  * applied; 32 = no directory, legacy sector migrated and loaded; 48 = nothing usable, factory defaults; negative DSPI_E_*. */
 int dspi_load_flash_dump(dspi_ctx *ctx, int32_t stream, const void *dump, size_t len);
 

@@ -26,6 +26,8 @@ void orc_set_fma_mode(int on);              /* float contract of the restated co
                                              * restated orchestrator */
 
 orc_ctx *orc_new(void);          /* power-on state: factory defaults, 44.1 kHz, host volume 0 dB */
+orc_ctx *orc_new_from_flash(const void *dump48k, uint32_t len, int *selection);   /* power-on of a device whose flash holds this preset area: no first-boot mute,
+                                                                                    * the selected preset applied the boot path's way (flash_storage.c:1047-1082) */
 void orc_free(orc_ctx *);
 
 int orc_set_sample_rate(orc_ctx *, uint32_t hz);        /* 44100 / 48000 / 96000, else -1 */

@@ -1074,7 +1074,13 @@ void orc_set_math_mode(int detmath) { orc_math_mode = detmath; }
 void orc_set_x86_cast_semantics(int on) { orc_x86_cast_semantics = on; }
 void orc_set_fma_mode(int on) { orc_fma_mode = (on != 0) && PICO_RP2350; }
 
-orc_ctx *orc_new(void) {
+static int flash_select_(orc_ctx *c, const void *dump, int booting, int *wrote);
+
+/* The power-on sequence.  `dump` NULL: an erased flash (first boot: preset_boot_load writes the fresh directory, which arms the mute).
+ * Otherwise the device boots from that 48 KB preset area: preset_boot_load's selection, applied the boot path's way — apply_slot_to_live /
+ * apply_factory_defaults and nothing else (flash_storage.c:1047-1082: no flash write, no mute, the delay lines untouched).  PINNED by the
+ * firmware build booted from the same dumps, from the first frame (tests/test_oracle_vs_fw.py::test_boot_from_flash_dumps). */
+static orc_ctx *orc_boot_(const void *dump, int *sel) {
     unsigned csr = orc_enter();
     orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
     /* power-on values of the globals (usb_audio.c:47, :148-211, :457) */
@@ -1097,8 +1103,17 @@ orc_ctx *orc_new(void) {
     /* core0_init (main.c:645-696): preset_boot_load on blank flash = factory defaults, and the fresh directory is written
      * (flash_storage.c:1097-1100): flash_write_sector re-arms the preset mute for flash_mute_hold_samples() = max(10 ms, 512)
      * samples at the power-on 44.1 kHz (:262-266, :349-350) — found by running the firmware build (tests/test_oracle_vs_fw.py) */
-    prepare_pipeline_reset(c, 512);
+    if (!dump) prepare_pipeline_reset(c, 512);
+    else {
+        /* a boot that WRITES the flash arms the same mute: no directory (legacy migration or a fresh directory, flash_storage.c:1084-1104)
+         * or a v1 directory, which dir_load_cache persists as v2 (:391-414) */
+        int wrote = 0, r = flash_select_(c, dump, 1, &wrote);
+        if (sel) *sel = r;
+        if (wrote) prepare_pipeline_reset(c, 512);
+    }
     recalculate_all_filters(c, 48000.0f); update_delay_samples(c, 48000.0f);
+    /* slots the preset saved as I2S go through process_type_switches before Core 1 starts (main.c:651-684): prepare_pipeline_reset(PRESET_MUTE_SAMPLES), :279 */
+    for (int i = 0; i < NUM_SPDIF_INSTANCES; i++) if (c->output_types[i] != 0) { prepare_pipeline_reset(c, PRESET_MUTE_SAMPLES); break; }
     loudness_recompute(c, 48000.0f); c->loudness_recompute_pending = false;
     if (c->loudness_enabled) set_volume_(c, c->audio_state.volume);
     LEAF(leveller_compute_coefficients)(&c->leveller_coeffs, &c->leveller_config, 48000.0f);
@@ -1111,6 +1126,12 @@ orc_ctx *orc_new(void) {
     service(c);
     orc_leave(csr);
     return c;
+}
+
+orc_ctx *orc_new(void) { return orc_boot_(NULL, NULL); }
+orc_ctx *orc_new_from_flash(const void *dump48k, uint32_t len, int *selection) {      /* selection: orc_load_flash_dump's codes */
+    if (!dump48k || len < 12u * 4096u) return NULL;
+    return orc_boot_(dump48k, selection);
 }
 
 void orc_free(orc_ctx *c) { free(c); }
@@ -1221,9 +1242,26 @@ typedef struct __attribute__((packed)) {
 #define PRESET_STARTUP_LAST_ACTIVE 1   /* config.h:259 */
 #endif
 
+/* a validated slot into the live parameters, nothing else (validate_slot + apply_slot_to_live + apply_master_volume_from_mode) */
+static int slot_to_live_(orc_ctx *c, const void *image, int expect_slot) {
+    OrcPresetSlot s; memcpy(&s, image, sizeof s);
+    bool ok = (s.magic == SLOT_MAGIC) && (expect_slot < 0 || s.slot_index == (uint16_t)expect_slot) &&
+              crc32_((const uint8_t *)&s.filter_recipes, sizeof(OrcPresetSlot) - offsetof(OrcPresetSlot, filter_recipes)) == s.crc32;
+    if (!ok) return PRESET_ERR_CRC;
+    apply_slot_to_live(c, &s, c->dir_include_pins != 0);
+    apply_master_volume_from_mode(c, &s);
+    return PRESET_OK;
+}
+
 int orc_load_flash_dump(orc_ctx *c, const void *dump, uint32_t len) {
     if (len < 12u * ORC_SECTOR) return -4;
+    return flash_select_(c, dump, 0, NULL);
+}
+
+/* booting: the application is the boot path's (apply_slot_to_live / apply_factory_defaults, flash_storage.c:1066-1076); else preset_load's */
+static int flash_select_(orc_ctx *c, const void *dump, int booting, int *wrote) {
     const uint8_t *p = (const uint8_t *)dump;
+    if (wrote) *wrote = 1;
     OrcDirV2 d2; memcpy(&d2, p, sizeof d2);
     int have_dir = 0;
     if (d2.magic == ORC_DIR_MAGIC) {
@@ -1232,7 +1270,7 @@ int orc_load_flash_dump(orc_ctx *c, const void *dump, uint32_t len) {
         } else if (d2.version == 1) {
             OrcDirV1 d1; memcpy(&d1, p, sizeof d1);
             if (crc32_((const uint8_t *)&d1.startup_mode, sizeof d1 - offsetof(OrcDirV1, startup_mode)) == d1.crc32) {
-                have_dir = 1;
+                have_dir = 2;
                 d2.startup_mode = d1.startup_mode; d2.default_slot = d1.default_slot; d2.last_active_slot = d1.last_active_slot;
                 d2.include_pins = d1.include_pins; d2.slot_occupied = d1.slot_occupied;
                 d2.master_volume_mode = d1.include_master_volume ? MASTER_VOLUME_MODE_WITH_PRESET : MASTER_VOLUME_MODE_INDEPENDENT;
@@ -1241,12 +1279,14 @@ int orc_load_flash_dump(orc_ctx *c, const void *dump, uint32_t len) {
         }
     }
     if (have_dir) {
+        if (wrote) *wrote = have_dir == 2;      /* (a v1 directory is written back as v2) */
         uint8_t target = d2.startup_mode == PRESET_STARTUP_LAST_ACTIVE ? d2.last_active_slot : d2.default_slot;
         if (target >= PRESET_SLOTS) { target = d2.default_slot; if (target >= PRESET_SLOTS) target = 0; }
         c->dir_master_volume_mode = d2.master_volume_mode; c->dir_master_volume_db = d2.master_volume_db; c->dir_include_pins = d2.include_pins;
         if (d2.slot_occupied & (1u << target))
-            if (orc_load_preset_slot(c, p + (1u + target) * ORC_SECTOR, sizeof(OrcPresetSlot), target) == PRESET_OK) return target;
-        orc_factory_defaults(c);
+            if ((booting ? slot_to_live_(c, p + (1u + target) * ORC_SECTOR, target)
+                         : orc_load_preset_slot(c, p + (1u + target) * ORC_SECTOR, sizeof(OrcPresetSlot), target)) == PRESET_OK) return target;
+        if (booting) apply_factory_defaults(c); else orc_factory_defaults(c);
         return 16 + target;
     }
     const uint8_t *lg = p + 11u * ORC_SECTOR;
@@ -1260,12 +1300,12 @@ int orc_load_flash_dump(orc_ctx *c, const void *dump, uint32_t len) {
         s.magic = SLOT_MAGIC; s.version = version; s.slot_index = 0;
         s.crc32 = crc32_((const uint8_t *)&s.filter_recipes, sizeof(OrcPresetSlot) - offsetof(OrcPresetSlot, filter_recipes));
         c->dir_include_pins = 0;
-        int rc = orc_load_preset_slot(c, &s, sizeof s, 0);
+        int rc = booting ? slot_to_live_(c, &s, 0) : orc_load_preset_slot(c, &s, sizeof s, 0);
         c->dir_include_pins = 1;
         if (rc == PRESET_OK) return 32;
     }
     c->dir_include_pins = 1;
-    orc_factory_defaults(c);
+    if (booting) apply_factory_defaults(c); else orc_factory_defaults(c);
     return 48;
 }
 

@@ -78,6 +78,9 @@ def load(flavor: int, ref=False, fma: bool = False) -> C.CDLL:
     lib.orc_load_preset_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
     lib.orc_save_preset_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     if hasattr(lib, "orc_load_flash_dump"): lib.orc_load_flash_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    if hasattr(lib, "orc_new_from_flash"):
+        lib.orc_new_from_flash.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
+        lib.orc_new_from_flash.restype = C.c_void_p
     lib.orc_vendor_set.argtypes = [C.c_void_p, C.c_uint8, C.c_uint16, C.c_void_p, C.c_uint16]
     lib.orc_vendor_get.argtypes = [C.c_void_p, C.c_uint8, C.c_uint16, C.c_void_p, C.c_uint16]
     lib.orc_get_status.argtypes = [C.c_void_p, C.c_void_p]
@@ -106,7 +109,8 @@ class Oracle:
         """ref: False = standalone restatement, True = reference leaf sources (_ref), "fw" = firmware build (ref_fw.c).
         fma: the firmware's float contract (contraction on).  The standalone build switches at run time
         (orc_set_fma_mode, explicit fmaf in the pattern GCC produces); the reference builds are separate libraries.
-        flash: (fw only) boot from this 48 KB preset area instead of an erased flash."""
+        flash: boot from this 48 KB preset area instead of an erased flash (the firmware build runs the reference's own core0_init /
+        preset_boot_load over it; the restatement its orc_new_from_flash: `boot_selection` holds preset_boot_load's choice)."""
         fma = bool(fma or getattr(flavor, "fma", False))      # wire.F32_FMA: the int 1 carrying the contract
         flavor = int(flavor)
         self.lib = load(flavor, ref, fma if ref else False)
@@ -117,8 +121,15 @@ class Oracle:
         self.C = self.lib.orc_num_channels()
         self.N = self.lib.orc_num_outputs()
         self.P = self.lib.orc_num_pairs()
+        self.boot_selection = None
+        if flash is not None and ref != "fw":
+            sel = C.c_int(-1)
+            self.h = self.lib.orc_new_from_flash(flash, len(flash), C.byref(sel))
+            assert self.h, "orc_new_from_flash"
+            self.boot_selection = sel.value
+            return
         if flash is not None:
-            assert ref == "fw" and self.lib.orc_boot_from_flash(flash, len(flash)) == 0
+            assert self.lib.orc_boot_from_flash(flash, len(flash)) == 0
         self.h = self.lib.orc_new()
 
     def _sync(self):

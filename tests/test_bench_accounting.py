@@ -17,15 +17,21 @@ spec.loader.exec_module(bench)
 
 def test_algorithmic_bytes():
     w = bench.chain_workload("3")
-    full, span = bench.algorithmic_bytes(w, 50 * 96)
-    assert full == 104.0                          # 4 in + 8 x 4 S/PDIF words + 4 sub + 8 x 8 delayed outputs (write + read)
-    assert 55.0 < span < 65.0                     # delays shorter than the 4 800-frame launch count only dly/T of their 8 bytes
-    assert bench.algorithmic_bytes(w, 10 ** 9)[1] < 41.0 and bench.algorithmic_bytes(w, 1)[1] == full
-    assert bench.algorithmic_bytes(bench.chain_workload("2"), 2000 * 48) == (12.0, 12.0)
-    q = bench.chain_workload("5")
-    assert bench.algorithmic_bytes(q, 50 * 48)[0] == 56.0      # 4 in + 4 x 4 words + 4 sub + 4 x 8 delayed outputs
+    a = bench.algorithmic_bytes(w, 50 * 96)
+    assert a["resident"] == 104.0                 # 4 in + 8 x 4 S/PDIF words + 4 sub + 8 x 8 delayed outputs (write + read)
+    assert 55.0 < a["span"] < 65.0                # delays shorter than the 4 800-frame launch count only dly/T of their 8 bytes
+    # the strict figure (roofline.frac): 40 + 4 * (sum of min(dly, T) over the 8 delayed outputs + 8 * min(4096, T)) / T with the lines'
+    # whole history kept — 48 + 96 + 192 + 480 + 960 + 1920 + 3840 + 4096 delay samples at 96 kHz
+    assert abs(a["exact"] - (40.0 + 4.0 * (11632 + 8 * 4096) / 4800.0)) < 1e-9 and 76.9 < a["exact"] < 77.1
+    assert a["span"] < a["exact"] < a["resident"]
+    big, one = bench.algorithmic_bytes(w, 10 ** 9), bench.algorithmic_bytes(w, 1)
+    assert big["span"] < 41.0 and big["exact"] < 41.0 and one["span"] == one["exact"] == one["resident"] == 104.0
+    assert bench.algorithmic_bytes(bench.chain_workload("2"), 2000 * 48) == dict(exact=12.0, resident=12.0, span=12.0)
+    q = bench.algorithmic_bytes(bench.chain_workload("5"), 50 * 48)
+    assert q["resident"] == 56.0                  # 4 in + 4 x 4 words + 4 sub + 4 x 8 delayed outputs
+    assert 24.0 < q["span"] < q["exact"] < 56.0   # 2 048-sample lines, 2 400-frame launches
     for name in ("perstream", "perstream_eq"):
-        assert bench.algorithmic_bytes(bench.chain_workload(name), 50 * 96)[0] == 104.0
+        assert bench.algorithmic_bytes(bench.chain_workload(name), 50 * 96)["resident"] == 104.0
 
 
 def test_profile_lookup_matches_the_variant():

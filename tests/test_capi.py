@@ -30,6 +30,14 @@ def test_argument_validation(product_lib):
     assert len(d.status()) == 18
     d2 = host.Dspi(1, 5, device=None)
     assert len(d2.status()) == 26 and d2.clear_clips() == 0
+    # dspi_process: undefined flag bits are refused (a later ABI may let a flag read further dspi_out members), before anything
+    # else is looked at; the defined ones pass the check (a host-only context then has no device: DSPI_E_NODEVICE)
+    out = host._Out(None, None, None, None)
+    buf = ctypes.create_string_buffer(5 * 48 * 4)
+    for bad in (0x40, 0x80, 0x100, 0x80000000, 0x3F | 0x400):
+        assert d2.L.dspi_process(d2.h, buf, 16, 1, 48, ctypes.byref(out), bad) == -10, hex(bad)
+    for ok in (0, 0x1, 0x3F):
+        assert d2.L.dspi_process(d2.h, buf, 16, 1, 48, ctypes.byref(out), ok) == -11, hex(ok)
 
 
 def test_no_oracle_in_product():

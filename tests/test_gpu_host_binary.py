@@ -42,3 +42,45 @@ def test_dspi_host_against_oracle(tmp_path, flavor, load):
     assert m and int(m.group(1)) == len(st)
     assert [int(v) for v in m.group(2).split()] == np.frombuffer(st[:o.C * 2], dtype="<u2").tolist()
     assert int(m.group(3), 16) == int.from_bytes(st[-2:], "little")
+
+
+def _xorshift_pcm(stream, frames):
+    """dspi_host's synthetic input for GLOBAL stream index `stream` (xorshift32 seeded 0x9E3779B9 ^ s * 2654435761, -6 dBFS)."""
+    x = (0x9E3779B9 ^ ((stream * 2654435761) & 0xFFFFFFFF)) & 0xFFFFFFFF
+    if not x: x = 1
+    out = np.empty(frames * 2, dtype=np.int16)
+    for i in range(frames * 2):
+        x ^= (x << 13) & 0xFFFFFFFF; x ^= x >> 17; x ^= (x << 5) & 0xFFFFFFFF
+        out[i] = ((x >> 16) % 32769) - 16384
+    return out.reshape(frames, 2)
+
+
+@pytest.mark.parametrize("flavor,scaling", [(W.F32_FMA, "weak"), (0, "strong")])
+def test_dspi_host_node_mode_through_rccl(tmp_path, flavor, scaling):
+    """dspi_host -g 1: the node-level run of the thin C host (one context + feeder thread per GPU, device buffers, thread barriers around the
+    timed calls) with its ONE collective on a real communicator — ncclCommInitAll + ncclAllReduce(sum frames, max seconds) over RCCL at
+    world size 1 (the only size a one-GPU box has; the partition at N > 1 is tests/test_host_binary_cpu.py).  The JSON line carries
+    bench.py's keys; device 0's first stream after the last call is checked against the oracle."""
+    fl = int(flavor)
+    fs, B, blocks, calls, warm, S = (96000, 96, 6, 3, 2, 300) if fl else (48000, 48, 8, 2, 1, 200)
+    ref = Oracle(flavor); assert ref.load_bulk(WL.full_chain_blob(fl)) == 0
+    (tmp_path / "bulk.bin").write_bytes(ref.collect_bulk())
+    r = subprocess.run([HOST, "-g", "1", "-S", scaling, "-w", str(warm), "-f", "f32fma" if fl else "q28", "-s", str(S), "-r", str(fs), "-b", str(B), "-n", str(blocks),
+                        "-c", str(calls), "-B", str(tmp_path / "bulk.bin"), "-v", "-20", "-o", str(tmp_path / "pairs.raw")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    import json
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["steps"] == calls and d["warmup"] == warm and d["scaling"] == scaling and d["dry_run"] is False
+    assert d["dist"]["backend"].startswith("rccl") and d["dist"]["world_size"] == 1
+    assert d["config"]["shards"] == [[0, S]] and d["config"]["frames"] == S * blocks * B * calls
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["frames_per_s"] * d["config"]["channels"]) <= 1e-6 * d["value"]
+    assert abs(d["ms_per_step"] - d["config"]["seconds"] / calls * 1e3) < 1e-3
+    o = Oracle(flavor, detmath=True)
+    assert o.set_rate(fs) == 0
+    o.set_volume(-20 * 256)
+    assert o.load_bulk(ref.collect_bulk()) == 0
+    pcm = _xorshift_pcm(0, blocks * B)
+    for _ in range(warm + calls):
+        pairs, _, _, _ = o.process(pcm, blocks, B)
+    got = np.frombuffer((tmp_path / "pairs.raw").read_bytes(), dtype=np.int32).reshape(pairs.shape)
+    assert np.array_equal(got, pairs)

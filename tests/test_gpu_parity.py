@@ -1238,6 +1238,47 @@ def test_spdif_flag_on_every_context(flavor, S, B, monkeypatch):
     plain.close(); fused.close()
 
 
+def test_spdif_with_enabled_only_on_mixed_launches(monkeypatch):
+    """DSPI_OUT_SPDIF served in two passes (chain into a scratch chunk, encoder from there) together with DSPI_OUT_ENABLED_ONLY.
+    The encoder reads the WHOLE scratch, so every kernel of the launch — latency-layout workgroups next to packed / per-lane ones — must
+    have written the silent pairs' zero words there: the subframes are then those of the call without the flag, silent pairs included
+    (encoded silence, not whatever the scratch held).  The context: 2 200 streams with a leveller-on preset of their own each (too many for
+    the latency layout: the packed kernels), the last 200 on the shared preset with ONE live pair (BASELINE config 2's: the latency layout,
+    which honours DSPI_OUT_ENABLED_ONLY).  Device buffers pre-filled with garbage; two calls, so the first call's scratch is stale in the second."""
+    import torch
+    monkeypatch.delenv("DSPI_F32_LAYOUT", raising=False)
+    fs, B, blocks, S, own = 48000, 48, 4, 2400, 2200
+    dev = torch.device("cuda", 0)
+    full = Oracle(W.F32_FMA); assert full.load_bulk(WL.full_chain_blob(1)) == 0
+    full_blob = full.collect_bulk(); full.close()
+    ctxs = []
+    for _ in range(2):
+        d = Dspi(W.F32_FMA, S, device=0)
+        d.set_rate(fs); d.set_volume(-10 * 256); assert d.load_bulk(WL.config2_blob(False)) == 0
+        for s_ in range(own): assert d.load_bulk(full_blob, stream=s_) == 0
+        ctxs.append(d)
+    plain, only = ctxs
+    frames = B * blocks
+    base = WL.synth_pcm16(256, frames * 2, fs)
+    for c in range(2):
+        part = torch.from_numpy(np.ascontiguousarray(base[:, c * frames:(c + 1) * frames])).to(dev)
+        pcm = part.repeat((S + 255) // 256, 1, 1)[:S].contiguous()
+        a = torch.full((S, 4, frames, 4), 0x5A5A5A5A, dtype=torch.int32, device=dev); b = torch.full((S, 4, frames, 4), 0x13571357, dtype=torch.int32, device=dev)
+        sa = torch.empty((S, frames), dtype=torch.int32, device=dev); sb = torch.empty((S, frames), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        plain.process_device(pcm.data_ptr(), blocks, B, 16, a.data_ptr(), sa.data_ptr(), 0, spdif=True); plain.sync()
+        only.process_device(pcm.data_ptr(), blocks, B, 16, b.data_ptr(), sb.data_ptr(), 0, spdif=True, enabled_only=True); only.sync()
+        plan = only.launch_plan()
+        others = sum(v for k, v in plan.items() if not k.startswith("latency_layout"))
+        assert plan["latency_layout"] + plan["latency_layout_paired"] > 0 and others > 0, plan      # a mixed launch, hence two passes
+        assert torch.equal(a, b), (c, torch.nonzero(a != b)[:3].tolist())
+        ref, _ = orclib.spdif_encode(np.zeros((frames, 2), dtype=np.int32), (c * frames) % 192, fs)
+        for s_ in (own + 1, S - 1):      # the shared preset's silent pairs carry the subframes of silence
+            w = b[s_].cpu().numpy().view(np.uint32)
+            assert np.array_equal(w[2], ref) and np.array_equal(w[3], ref), s_
+    plain.close(); only.close()
+
+
 @pytest.mark.both_layouts
 def test_spdif_channel_status_follows_each_streams_rate():
     """the sample-rate byte of the IEC 60958 channel status (audio_spdif.c:250-256) belongs to the device.  A context whose
@@ -1296,9 +1337,11 @@ def test_boot_from_populated_flash_has_no_first_boot_mute(flavor):
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 def test_flash_dump_boots_device_context(flavor):
     """SURVEY 8f-4 on the GPU: dspi_load_flash_dump on a DEVICE context (v2 directory, v1 directory, corrupt selected slot -> factory
-    defaults, legacy "DSP1" sector -> migrated slot 0; flash_storage.c:1047-1105, :370-417, :997-1045), then audio.  Every word from
-    the first packet on against the restatement opened with the same dump (same preset-load mute), and, where oracle/_ref holds the
-    firmware build, the packets after the mutes have run out against the reference's own flash code BOOTED from that dump."""
+    defaults, legacy "DSP1" sector -> migrated slot 0; flash_storage.c:1047-1105, :370-417, :997-1045), then audio.  Two readings of the
+    call: on a running device (default context) it is a preset switch — every word from the first packet on against the restatement opened
+    with the same dump (same preset-load mute), the packets after the mutes against the firmware build booted from it; on a context of
+    devices with a populated flash that has played nothing it is the BOOT — every word from frame 0 against the restatement and the
+    firmware build booted from the dump."""
     from test_flash_dump import make_slots
     fl = int(flavor)
     slots = make_slots(fl); occ = sum(1 << n for n in slots)
@@ -1340,6 +1383,36 @@ def test_flash_dump_boots_device_context(flavor):
                 fw.close()
             o.close()
         d.close()
+        # The BOOT path: a context of devices with a populated flash that has not played anything boots from the dump (preset_boot_load ->
+        # apply_slot_to_live, flash_storage.c:1047-1082: no mute unless the boot itself writes the flash, no line zeroing) — every word
+        # FROM THE FIRST FRAME against the restatement booted from the dump and against the firmware build booted from it.
+        db = Dspi(flavor, S, device=0, populated_flash=True)
+        assert db.load_flash_dump(dump) == want
+        assert db.set_rate(fs) == 0
+        db.set_volume(-12 * 256)
+        bp, bs, bk = db.process_host(np.ascontiguousarray(pcm[:, :blocks * B]), blocks, B)
+        for s in (0, 5, 64, S - 1):
+            ob = Oracle(flavor, detmath=True, flash=dump)
+            assert ob.boot_selection == want and ob.set_rate(fs) == 0
+            ob.set_volume(-12 * 256)
+            rp, rs, rk, _ = ob.process(pcm[s][:blocks * B], blocks, B)
+            assert np.array_equal(rp, bp[s]) and np.array_equal(rs, bs[s]) and np.array_equal(rk, bk[s]), ("boot path", want, s)
+            assert ob.status() == db.status(s) and ob.collect_bulk() == db.collect_bulk(s)
+            if s == 0: ob0 = ob
+            else: ob.close()
+            if have_fw and s in (0, 64):
+                fw = Oracle(fl, ref="fw", flash=dump, fma=fma)
+                assert fw.set_rate(fs) == 0
+                fw.set_volume(-12 * 256)
+                fp, fsub, fk, _ = fw.process(pcm[s][:blocks * B], blocks, B)
+                assert np.array_equal(fp, bp[s]) and np.array_equal(fsub, bs[s]) and np.array_equal(fk, bk[s]), ("firmware build, from frame 0", want, s)
+                fw.close()
+        # once audio has run the same call is a preset switch on a running device again (preset_load: mute, lines zeroed)
+        assert db.load_flash_dump(dump) == want and ob0.load_flash_dump(dump) == want
+        ap, asub, ak = db.process_host(np.ascontiguousarray(pcm[:, blocks * B:(blocks + 12) * B]), 12, B)
+        rp, rs, rk, _ = ob0.process(pcm[0][blocks * B:(blocks + 12) * B], 12, B)
+        assert np.array_equal(rp, ap[0]) and np.array_equal(rs, asub[0]) and np.array_equal(rk, ak[0]), ("preset switch after the boot", want)
+        ob0.close(); db.close()
 
 
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)

@@ -269,6 +269,25 @@ def _boot_both(flavor, dump):
     pcm = signal(48, 120, 48000, 4, 16)
     fw.process(pcm, 120, 48); o.process(pcm, 120, 48)
     same_audio(o, fw, signal(48, 20, 48000, 9, 16), 20, 48, 16, "after boot")
+    # The BOOT itself (preset_boot_load -> apply_slot_to_live, flash_storage.c:1047-1082: no mute unless the boot writes the flash, no line
+    # zeroing): the restatement booted from the dump (orc_new_from_flash) and a host-only product context of devices with a populated flash
+    # (DSPI_BOOT_POPULATED_FLASH + dspi_load_flash_dump before any audio) against a second firmware instance booted from it — parameters,
+    # state taps, and every word FROM THE FIRST FRAME.
+    fw2 = Oracle(flavor, ref="fw", flash=dump)
+    ob = Oracle(flavor, x86_casts=True, flash=dump)
+    db = Dspi(flavor, 2, device=None, populated_flash=True)
+    assert ob.boot_selection == rc_o and db.load_flash_dump(dump) == rc_o
+    for x in (fw2, ob, db):
+        assert x.set_rate(48000) == 0
+        x.set_volume(-9 * 256)
+    assert fw2.collect_bulk() == ob.collect_bulk() == db.collect_bulk(), "parameter blob after the boot path"
+    assert fw2.save_slot(2) == ob.save_slot(2) == db.save_slot(2)
+    for t in (0, 1, 2, 3, 4, 5, 7):
+        assert fw2.tap(t) == ob.tap(t), f"state tap {t} after the boot path"
+    for k in (0, 1, 2, 4, 5, 6, 7, 8, 9):
+        assert fw2.scalar(k) == ob.scalar(k), f"scalar {k} after the boot path"
+    same_audio(ob, fw2, signal(48, 40, 48000, 11, 16), 40, 48, 16, "from the first frame after booting from the dump")
+    fw2.close(); ob.close(); db.close()
     return rc_o, fw, o
 
 
