@@ -839,6 +839,80 @@ def test_full_size_properties(flavor):
     d.close()
 
 
+@pytest.mark.parametrize("flavor,fs,B,S,tiled", [(W.F32_FMA, 96000, 96, 65536, False), (W.F32_FMA, 96000, 96, 65536, True), (1, 96000, 96, 65536, False), (0, 48000, 48, 16384, False)])
+def test_full_size_distinct_input_sampled_across_every_workgroup(flavor, fs, B, S, tiled, monkeypatch):
+    """the full-size checks above feed every workgroup the SAME streams, so a defect that needs distinct data in
+    distinct workgroups under full occupancy (an address carry past 4 GB in the 9.66 GB line array with per-row content, a row reading
+    its neighbour's ring) would be seen by a handful of streams only.  Here: BASELINE config 3 (Q28: config 5) at its own size, the
+    SURVEY 8d input mix with DISTINCT noise per stream (generated on the device), three launches of 14 packets — shorter than four of the
+    delays, so every launch reads what the one before left in the lines — and ONE stream of EVERY workgroup row (lane and lane half
+    varying from row to row: 512 rows float, 256 Q28; the rows from 228 on lie beyond 4 GB in the line array) plus one stream of every
+    input class checked against the oracle: every pair word, sub word and peak of every launch, status bytes and clip flags at the end."""
+    import importlib.util
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    if S == 16384: monkeypatch.delenv("DSPI_Q28_WAVES", raising=False)
+    spec = importlib.util.spec_from_file_location("dspi_bench_for_tests", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    fl = int(flavor)
+    blocks, calls = 14, 3
+    n_out, n_ch, P = (9, 11, 4) if fl else (5, 7, 2)
+    dev = torch.device("cuda", 0)
+    blob = WL.full_chain_blob(fl)
+    d = Dspi(flavor, S, device=0)
+    d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(blob) == 0
+    R = d.tile_streams(); rows = S // R
+    frames = B * blocks
+    if fl:      # the lines of the last rows start beyond 4 GB (9 outputs x 4 096 positions x 128 streams x 4 B per row)
+        assert (rows - 1) * 9 * 4096 * R * 4 > (1 << 32)
+    sample = sorted({r * R + (37 * r + 5) % R for r in range(rows)} | {14, 15, 16, 17, 18, 19, S // 2 // 20 * 20 + 18, S // 2 // 20 * 20 + 19, S - 1})
+    idx = torch.tensor(sample, device=dev)
+    got = []
+    clip = torch.empty((S,), dtype=torch.int16, device=dev)
+    pcm_all = bench.synth_device(torch, dev, S, frames * calls, fs, 4321, True)      # one buffer over the three launches: the classes (sweep, bursts, square) run through
+    host_pcm = pcm_all[idx].cpu().numpy()
+    for c in range(calls):
+        pcm = pcm_all[:, c * frames:(c + 1) * frames].contiguous()
+        if tiled:
+            pairs = torch.empty((rows, n_out - 1, frames, R), dtype=torch.int32, device=dev); sub = torch.empty((rows, frames, R), dtype=torch.int32, device=dev)
+        else:
+            pairs = torch.empty((S, P, frames, 2), dtype=torch.int32, device=dev); sub = torch.empty((S, frames), dtype=torch.int32, device=dev)
+        peaks = torch.empty((S, blocks, n_ch), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        d.process_device(pcm.data_ptr(), blocks, B, 16, pairs.data_ptr(), sub.data_ptr(), peaks.data_ptr(), tiled=tiled, clip_ptr=clip.data_ptr()); d.sync()
+        if tiled:
+            gp = pairs[idx // R, :, :, idx % R].cpu().numpy().reshape(len(sample), P, 2, frames).transpose(0, 1, 3, 2)
+            gs = sub[idx // R, :, idx % R].cpu().numpy()
+        else:
+            gp, gs = pairs[idx].cpu().numpy(), sub[idx].cpu().numpy()
+        got.append((gp, gs, peaks[idx].cpu().numpy().view(np.uint16)))
+        del pairs, sub, peaks, pcm
+    clip_h = clip[idx].cpu().numpy().view(np.uint16)
+    status = [d.status(s) for s in sample]
+
+    def one(j):
+        o = Oracle(flavor, detmath=True)
+        assert o.set_rate(fs) == 0
+        o.set_volume(-20 * 256)
+        assert o.load_bulk(blob) == 0
+        res = [o.process(np.ascontiguousarray(host_pcm[j][c * frames:(c + 1) * frames]), blocks, B, 16) for c in range(calls)]
+        st = o.status(); o.close()
+        return res, st
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        refs = list(ex.map(one, range(len(sample))))
+    for j, s in enumerate(sample):
+        res, st = refs[j]
+        for c in range(calls):
+            rp, rs, rk, rclip = res[c]
+            assert np.array_equal(rp, got[c][0][j]), f"pair words differ: stream {s} (row {s // R}), launch {c}: {np.argwhere(rp != got[c][0][j])[:3].tolist()}"
+            assert np.array_equal(rs, got[c][1][j]), f"sub words differ: stream {s} (row {s // R}), launch {c}"
+            assert np.array_equal(rk, got[c][2][j]), f"peaks differ: stream {s} (row {s // R}), launch {c}"
+        assert st == status[j], f"status bytes differ: stream {s}"
+        assert int(clip_h[j]) == int.from_bytes(st[-2:], "little") == res[-1][3], f"clip flags differ: stream {s}"
+    assert len(sample) >= (512 if fl else 256)
+    d.close()
+
+
 @pytest.mark.parametrize("flavor,fs,B,S", [(1, 96000, 96, 65536), (1, 44100, 45, 65536), (1, 48000, 16, 65536), (W.F32_FMA, 96000, 96, 65536), (W.F32_FMA, 44100, 45, 65536),
                                           (0, 48000, 48, 65536), (0, 44100, 44, 65536), (0, 48000, 16, 65536), (0, 48000, 20, 65536), (0, 48000, 7, 65536),
                                           (0, 48000, 48, 16384), (0, 44100, 45, 16384)])
