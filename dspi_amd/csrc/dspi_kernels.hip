@@ -21,6 +21,7 @@
 // packet).  Pass 1 of packet k and pass 2 of packet k-1 are interleaved chunk by chunk through a [2][1024][stream]
 // ring in HBM that doubles as the 480-sample lookahead line, so no wave ever holds more than one chunk in registers.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1144,6 +1145,7 @@ __device__ __forceinline__ void output_item_q28(const KArgs &a, IMG img, const S
     if (cq == g.cpb - 1 && (flags & IF_ANY_DELAY)) s.widx = (s.widx + g.B) & ((uint32_t)sm.max_delay - 1u);
 }
 
+#include "dspi_chain_q28_lat.inc"
 #include "dspi_chain_pk.inc"
 #include "dspi_chain_skew.inc"
 #include "dspi_chain_skew_lev.inc"
@@ -1541,8 +1543,20 @@ static uint32_t q28_seven_wave_limit() {      // work items up to which the seve
     return (uint32_t)cus[dev];
 }
 
+// Q28 contexts small enough to leave the chip underfilled take the latency layout (dspi_chain_q28_lat.inc: one stream per workgroup, one
+// lane per (channel, stage)): up to four of its two-wave workgroups per CU.  DSPI_Q28_LAYOUT=lat|chain forces one (tests, development).
+static uint32_t q28_latency_limit() {
+    if (const char *e = getenv("DSPI_Q28_LAYOUT")) { if (!strcmp(e, "lat")) return 0xffffffffu; if (!strcmp(e, "chain")) return 0u; }
+    return 4u * q28_seven_wave_limit();
+}
 template <int FLAVOR, bool PL, bool FMA = false>
 static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
+    if constexpr (FLAVOR == 0) {
+        if (args.n_streams <= q28_latency_limit() && getenv("DSPI_Q28_WAVES") == nullptr) {
+            hipLaunchKernelGGL((chain_kernel_q28_lat<PL>), dim3(n_items * 64u), dim3(128), 0, stream, args);
+            return hipGetLastError();
+        }
+    }
     if constexpr (FLAVOR == 0) { if (n_items <= q28_seven_wave_limit()) return launch_chain_q28_7<PL>(args, n_items, stream); }
     const size_t lds = chain_lds_bytes(FLAVOR, 0);
     // the dynamic-LDS limit is a per-device function attribute: remember it per device (contexts on several GPUs may

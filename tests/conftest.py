@@ -27,13 +27,15 @@ def product_lib():
 
 @pytest.fixture(autouse=True)
 def q28_wave_layout(request, monkeypatch):
-    """The Q28 chain kernel has two wave layouts, chosen by launch size (dspi_kernels.hip chain_kernel NW: seven waves up to one
-    workgroup per CU, four beyond).  Test-sized launches would all take the first; so every other GPU test (by a hash of its id)
-    forces the four-wave layout, and the suite covers both with everything it has.  test_q28_wave_layouts sets its own."""
-    if request.node.get_closest_marker("gpu") and "DSPI_Q28_WAVES" not in os.environ:
+    """The Q28 chain runs on three kernels, chosen by size: the latency layout (dspi_chain_q28_lat.inc: one stream per workgroup) for
+    contexts that leave the chip underfilled, and chain_kernel's two wave layouts beyond (seven waves up to one workgroup per CU, four
+    beyond).  Test-sized contexts would all take the first; so by a hash of the test's id a third of the GPU tests force the four-wave
+    layout and a third the seven-wave one (DSPI_Q28_WAVES, which also keeps the latency layout out), and the suite covers all three with
+    everything it has.  test_q28_wave_layouts sets its own."""
+    if request.node.get_closest_marker("gpu") and "DSPI_Q28_WAVES" not in os.environ and "DSPI_Q28_LAYOUT" not in os.environ:
         import zlib
-        if zlib.crc32(request.node.nodeid.encode()) & 1:
-            monkeypatch.setenv("DSPI_Q28_WAVES", "4")
+        h = zlib.crc32(request.node.nodeid.encode()) % 3
+        if h: monkeypatch.setenv("DSPI_Q28_WAVES", "4" if h == 1 else "7")
     yield
 
 
