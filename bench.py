@@ -31,7 +31,8 @@ What a line says (config 3):
   cpu_baseline  the reference C path on this box's host cores (a reported baseline, not the target)
   realtime_call  (default configuration, N=1) the call as the firmware makes it: ONE packet per dspi_process(), host buffers, one stream
               of the same preset, through the C host (dspi_host -rt): p50 / p99 us per call, every word of every call checked against
-              the oracle.  Reported beside the batched figure; never part of `value`.
+              the oracle.  Reported beside the batched figure; never part of `value`.  `realtime_call_q28`: the same for the RP2040 Q28
+              flavour (one 48-frame packet at 48 kHz, BASELINE config 5's preset).
 """
 from __future__ import annotations
 
@@ -670,6 +671,15 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
                                     "max_us": r["max_us"], "packet_us": r["packet_us"], "over_packet_time": r["over_packet_time"], "parity": r.get("parity")}
         except BaseException as e:  # a missing dspi_host binary must not cost the line
             out["realtime_call"] = {"what": "one packet per dspi_process()", "p50_us": None, "error": str(e)[:200]}
+        # ... and the RP2040 Q28 flavour's: one 48-frame packet at 48 kHz, one stream of BASELINE config 5's preset (the integer chain's latency
+        # layout, dspi_chain_q28_lat.inc), every word of every call checked against the oracle
+        try:
+            from dspi_amd import workloads as WL
+            r = bench_realtime.run("q28", 0, 1, 48000, 48, 3000, 1000, check=True)
+            out["realtime_call_q28"] = {"what": "one packet per dspi_process(), host buffers, one stream of BASELINE config 5's preset (dspi_host -rt -f q28)", "calls": r["calls"], "p50_us": r["p50_us"],
+                                        "p99_us": r["p99_us"], "max_us": r["max_us"], "packet_us": r["packet_us"], "over_packet_time": r["over_packet_time"], "parity": r.get("parity")}
+        except BaseException as e:
+            out["realtime_call_q28"] = {"what": "one packet per dspi_process(), Q28", "p50_us": None, "error": str(e)[:200]}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(flavor, FS, B, w["blob"], CH, args.contract == "fma" and flavor == 1, w["vol"], f"config {args.config}")

@@ -1544,10 +1544,12 @@ static uint32_t q28_seven_wave_limit() {      // work items up to which the seve
 }
 
 // Q28 contexts small enough to leave the chip underfilled take the latency layout (dspi_chain_q28_lat.inc: one stream per workgroup, one
-// lane per (channel, stage)): up to four of its two-wave workgroups per CU.  DSPI_Q28_LAYOUT=lat|chain forces one (tests, development).
+// lane per (channel, stage)): up to eight of its two-wave workgroups per CU — 2 048 streams on 256 CUs, where it is still ahead for one-packet
+// and for 50-packet calls alike; at 4 096 chain_kernel wins (tools/bench_q28_layouts.py, profiles/r05_q28_layouts.jsonl).
+// DSPI_Q28_LAYOUT=lat|chain forces one (tests, development).
 static uint32_t q28_latency_limit() {
     if (const char *e = getenv("DSPI_Q28_LAYOUT")) { if (!strcmp(e, "lat")) return 0xffffffffu; if (!strcmp(e, "chain")) return 0u; }
-    return 4u * q28_seven_wave_limit();
+    return 8u * q28_seven_wave_limit();
 }
 template <int FLAVOR, bool PL, bool FMA = false>
 static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
