@@ -396,6 +396,45 @@ def test_q28_wave_layouts(waves, monkeypatch):
     compare(0, 44100, 45, 20, 70, WL.full_chain_blob(0), depth=24, calls=2, first_stream=15)
 
 
+@pytest.mark.parametrize("lev", [1, 0])
+def test_q28_latency_layout_alternates_with_the_chain_kernels(lev, monkeypatch):
+    """The Q28 latency layout (dspi_chain_q28_lat.inc: one stream per workgroup, one lane per (channel, stage)) shares the state array, the
+    delay lines and the leveller ring with chain_kernel<0>: a context changes kernels between two calls when its size or the caller's
+    packet count moves it.  One context, SEVEN calls, the kernel forced per call — latency, four waves, latency, seven waves, ... —
+    ragged 45-frame packets, one-packet calls in between, delays at the corners of the 2 048-sample lines, per-stream presets (rows with
+    several images), leveller with look-ahead on / off: every word, peak and status byte of every stream against the oracle; then the
+    size rule itself (nothing forced: a context of this size takes the latency layout)."""
+    fs, B, S = 44100, 45, 70
+    b = WL.full_chain_blob(0)
+    max_ms = 2048 * 1000.0 / fs
+    for o, ms in enumerate([0.05, 0.3, max_ms + 1.0, max_ms - 0.05, 2.5]): b["outputs"][o]["delay_ms"] = ms
+    b["leveller"]["enabled"] = lev
+    plan = [("lat", None, 3), ("chain", "4", 2), ("lat", None, 1), ("chain", "7", 4), ("lat", None, 1), ("lat", None, 13), ("chain", "4", 1)]
+    total = sum(n for _, _, n in plan)
+    pcm = WL.synth_pcm16(S, B * total, fs, first_stream=11)
+    own = {3: -7.5, 64: 2.0, S - 1: -1.25}
+    d = Dspi(0, S, device=0)
+    assert d.set_rate(fs) == 0
+    d.set_volume(-12 * 256); assert d.load_bulk(b) == 0
+    for s_, db in own.items(): d.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", db), stream=s_)
+    outs, at = [], 0
+    for layout, waves, n in plan:
+        monkeypatch.setenv("DSPI_Q28_LAYOUT", layout)
+        if waves: monkeypatch.setenv("DSPI_Q28_WAVES", waves)
+        else: monkeypatch.delenv("DSPI_Q28_WAVES", raising=False)
+        outs.append(d.process_host(np.ascontiguousarray(pcm[:, at * B:(at + n) * B]), n, B))
+        at += n
+    pairs = np.concatenate([o[0] for o in outs], axis=2); sub = np.concatenate([o[1] for o in outs], axis=1); peaks = np.concatenate([o[2] for o in outs], axis=1)
+    for s_ in range(S):
+        setup = (lambda o, db=own[s_]: o.vendor_set(W.REQ["SET_PREAMP"], 0, struct.pack("<f", db))) if s_ in own else None
+        (rp, rs, rk, _), status = oracle_run(0, fs, -12 * 256, b, pcm[s_], total, B, 16, setup)
+        assert np.array_equal(rp, pairs[s_]) and np.array_equal(rs, sub[s_]) and np.array_equal(rk, peaks[s_]), s_
+        assert status == d.status(s_), s_
+    d.close()
+    monkeypatch.delenv("DSPI_Q28_LAYOUT", raising=False); monkeypatch.delenv("DSPI_Q28_WAVES", raising=False)
+    compare(0, 48000, 48, 12, 150, b, calls=3)
+
+
 @pytest.mark.both_layouts
 @pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
 @pytest.mark.parametrize("lev", [1, 0])
