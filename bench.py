@@ -630,6 +630,8 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         forced = os.environ.get("DSPI_Q28_WAVES")
         nw = int(forced) if forced in ("4", "7") else (7 if (S + 63) // 64 <= cus else 4)
         kname = "chain_kernel<0, false, false, false, %d>" % nw
+        lay = os.environ.get("DSPI_Q28_LAYOUT")      # contexts of up to eight streams per CU take the Q28 latency layout (dspi_kernels.hip q28_latency_limit)
+        if lay == "lat" or (lay != "chain" and forced not in ("4", "7") and S <= 8 * cus): kname = "chain_kernel_q28_lat<false>"
     roofline = roof(primary)
     roofline["kernel"] = kname
     for m in also:

@@ -16,6 +16,8 @@ run config_2b python bench.py --config 2b --no-cpu-baseline
 run config_5 python bench.py --config 5 --no-cpu-baseline
 run config_5_64k python bench.py --config 5 --streams 65536 --no-cpu-baseline
 run config3_512streams python bench.py --config 3 --streams 512 --no-cpu-baseline --no-variants
+run config_5_1024streams python bench.py --config 5 --streams 1024 --no-cpu-baseline
+python tools/bench_q28_layouts.py > $O/q28_layouts.jsonl 2>/dev/null
 run perstream python bench.py --config perstream --no-cpu-baseline
 run perstream_eq python bench.py --config perstream_eq --no-cpu-baseline
 DSPI_DEBUG=1 python bench.py --config perstream_eq --no-cpu-baseline > $O/bench_perstream_eq_every_band.json 2>/dev/null
@@ -24,6 +26,16 @@ run spdif python bench.py --config spdif
 run i2s python bench.py --config i2s
 run blocks200_tiled python bench.py --out-layout tiled --blocks-per-step 200 --no-cpu-baseline --no-variants
 python tools/bench_realtime.py --calls 10000 --presets config3,config3_leveller_off,config2 --out $O/realtime.json > $O/realtime.log 2>&1
+DSPI_Q28_LAYOUT=chain python tools/bench_realtime.py --calls 3000 --flavors q28 --out $O/realtime_q28_chain_kernel.json > $O/realtime_q28_chain_kernel.log 2>&1
+# the thin C host's node-level mode on the one GPU of this box: one context + feeder thread, the reduction through ncclCommInitAll / ncclAllReduce
+python -c "
+import sys; sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+from orclib import Oracle
+from dspi_amd import workloads as WL
+o = Oracle(1); assert o.load_bulk(WL.full_chain_blob(1)) == 0
+open('$O/config3_bulk.bin', 'wb').write(o.collect_bulk())
+"
+dspi_amd/csrc/dspi_host -g 1 -f f32fma -s 65536 -r 96000 -b 96 -n 50 -c 20 -w 5 -v -20 -B $O/config3_bulk.bin > $O/dspi_host_g1.json 2> $O/dspi_host_g1.err
 python tools/bench_small_contexts.py > $O/small_contexts_leveller_on.jsonl 2>/dev/null
 LEVELLER=0 python tools/bench_small_contexts.py > $O/small_contexts_leveller_off.jsonl 2>/dev/null
 SIZES=16,128,512,1024,2048,4096 PERSTREAM=1 python tools/bench_small_contexts.py > $O/small_contexts_per_stream_leveller_on.jsonl 2>/dev/null

@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH_ARGS="${BENCH_ARGS:-} --no-cpu-baseline --no-variants --no-parity"
+BENCH_ARGS="${BENCH_ARGS:-} --no-cpu-baseline --no-variants --no-parity --no-configs --no-realtime"
 BENCH="python bench.py --steps 3 --warmup 1 $BENCH_ARGS"
 timeout 240 rocprofv3 -L > $OUT/counters.txt 2>&1
 # the trace pass runs more steps so that the per-kernel average is the steady state bench.py times (the first launch of a
