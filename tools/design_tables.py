@@ -8,7 +8,7 @@ prose never carries numbers the profiles do not: rows between `<!-- table:NAME -
 import json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = os.path.join(ROOT, "profiles")
 
 
@@ -43,12 +43,13 @@ def headline():
             ("2 forced onto the packed kernel", "m", "`chain_kernel_pk`"),
             ("3's preset on 512 streams", "p", "`chain_kernel_skew_lev`"),
             ("5, Q28, 16 384 streams", "e", "`chain_kernel<0,…,7>`"), ("5 at 65 536 streams", "k", "`chain_kernel<0,…,4>`"),
+            ("5's preset on 1 024 streams", "q", "`chain_kernel_q28_lat` (section 4.4)"),
             ("65 536 presets, identical filters, stream-major", "f", "`chain_kernel_pk<…,PV>`"),
             ("65 536 presets, one master band each, tiled", "i", "`chain_kernel_pk<…,PV,PVB>`"),
             ("65 536 presets, one master band each, stream-major", "o", ""),
             ("65 536 presets, EVERY band differs, tiled", "n", ""),
             ("I2S slot words", "j", "`i2s_kernel`"), ("PDM modulator", "g", "`pdm_kernel`"), ("S/PDIF subframes", "h", "`spdif_kernel`")]
-    out = ["| config | kernel | ms / launch (rocprofv3) | algorithmic B/frame -> frac of 8 TB/s | moved B/frame (2 x FETCH + WRITE) | VALU issue | VALU wave-instructions per stream-frame x 64 |",
+    out = ["| config | kernel | ms / launch (rocprofv3) | algorithmic B/frame (HBM-resident rule, SURVEY 8d) -> frac of 8 TB/s | moved B/frame (2 x FETCH + WRITE) | VALU issue | VALU wave-instructions per stream-frame x 64 |",
            "|---|---|---|---|---|---|---|"]
     for label, letter, kern in rows:
         s = summary(letter)
@@ -60,10 +61,22 @@ def headline():
     if d:
         r = d["roofline"]
         extra.append(f"- `bench.py` (no flags, `profiles/bench_{TAG}_default.json`): **{d['ms_per_step']:.2f} ms** per launch = {d['config']['frames_per_s']:.3e} frames/s = "
-                     f"**{d['value']:.3e} samples/s**, `roofline.frac` **{r['frac']:.3f}** ({r['achieved']:.0f} GB/s algorithmic), {r['power_w']:.0f} W of "
-                     f"{r['power_cap_w']:.0f} W at {r['sclk_mhz']:.0f} MHz, {d.get('parity_checked', 0)} streams of the timed context checked against the oracle.")
+                     f"**{d['value']:.3e} samples/s**; `roofline.frac` **{r['frac']:.3f}** (STRICT: {r['algorithmic_bytes_per_frame']:.1f} B/frame, {r['achieved']:.0f} GB/s), "
+                     f"`frac_hbm_resident` {r['frac_hbm_resident']:.3f} (104 B), `frac_launch_span` {r['frac_launch_span']:.3f} (59.4 B); {r['power_w']:.0f} W of "
+                     f"{r['power_cap_w']:.0f} W at {r['sclk_mhz']:.0f} of {r.get('sclk_max_mhz') or 0:.0f} MHz -> binds: {r['binds']}; {d.get('parity_checked', 0)} streams of the timed context checked against the oracle.")
         for a in d.get("also", []):
-            extra.append(f"- also: {a['contract']}, {a['out_layout']}, {a['input']}: {a['ms_per_step']:.2f} ms, frac {a['roofline_frac']:.3f}")
+            extra.append(f"- also: {a['contract']}, {a['out_layout']}, {a['input']}: {a['ms_per_step']:.2f} ms, frac {a['roofline_frac']:.3f} (HBM-resident rule: {a.get('roofline_frac_hbm_resident', 0):.3f})")
+        for name, c in (d.get("configs") or {}).items():
+            if "error" in c: extra.append(f"- config {name} (same line): {c['error']}"); continue
+            rr = c["roofline"]
+            extra.append(f"- config {name} in the same line ({c['streams']} streams x {c['blocks_per_step']} packets, {c['steps']} timed launches after {c['warmup']} + {c['preload_steps']}): "
+                         f"**{c['ms_per_step']:.2f} ms** per launch, {c['frames_per_s']:.3e} frames/s, {c['realtime_streams']:.0f} real-time streams, frac {rr['frac']:.3f}, "
+                         f"VALU issue at the clock {rr.get('valu_fraction_at_sclk') or 0:.2f}, {rr.get('sclk_mhz') or 0:.0f} MHz, binds: {rr['binds']}, `{rr['kernel']}`, {c['parity_checked']} streams checked")
+        for key in ("realtime_call", "realtime_call_q28"):
+            rt = d.get(key)
+            if rt and rt.get("p50_us"): extra.append(f"- `{key}`: p50 {rt['p50_us']:.1f} us, p99 {rt['p99_us']:.1f} us, max {rt['max_us']:.0f} us over {rt['calls']} calls; {rt.get('parity')}")
+        cb = d.get("cpu_baseline")
+        if cb and cb.get("value"): extra.append(f"- `cpu_baseline`: {cb['value']:.3e} samples/s on {cb['cores']} host threads ({cb['kind']}), single core {cb.get('single_core_realtime_x', 0):.1f} x real time")
     for name, what in (("steps200", "200 timed launches"), ("blocks200_tiled", "200 packets per launch, tiled words")):
         b = bench(name)
         if b: extra.append(f"- {what} (`bench_{TAG}_{name}.json`): {b['ms_per_step']:.2f} ms per launch of {b['config']['blocks_per_step']} packets, frac {b['roofline']['frac']:.3f}")
