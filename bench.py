@@ -306,6 +306,48 @@ def latest_profile(kernel_key, contract, layout):
     return best
 
 
+def latest_power_model():
+    """profiles/power_model_r*.json (tools/ablate_power.py at the round's HEAD): joules per frame of the chain's arithmetic alone and joules per
+    HBM byte of a streaming copy, both measured on the builder's box through the same sampler as roofline.power_w."""
+    best = None
+    for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "power_model_r*.json"))):
+        try:
+            t = json.load(open(pth))
+            if t.get("arith_j_per_frame") and t.get("hbm_j_per_byte"): best = dict(t, source=os.path.basename(pth))
+        except Exception:
+            continue
+    return best
+
+
+def side_run(extra, env=None, timeout=600):
+    """bench.py run again as a child (same box, minutes apart) for one more variant of config 3: returns the child's line (dict) or an error record."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-variants", "--no-realtime", "--no-configs", "--no-side-runs"] + extra
+    e = dict(os.environ, **(env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSPI_BENCH_FORCE_DIST"): e.pop(k, None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            if "PARITY FAILURE" in (r.stdout + r.stderr): raise SystemExit("bench.py: PARITY FAILURE in a side run: " + " ".join(extra))
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout"}
+
+
+RT_CALLS = 30000      # one-packet calls per flavour in the default line (VERDICT r05 item 3: a 1-in-3 000 outlier needs more than 3 000 calls to be seen twice)
+
+
+def rt_record(what, r):
+    """The one-packet-per-call record of the line: percentiles AND the tail (calls longer than the packet they carry, log2 histogram, the worst
+    calls' indices, the library's polling record)."""
+    keys = ("calls", "p50_us", "p99_us", "p99_9_us", "p99_99_us", "max_us", "packet_us", "over_packet_time", "n_over_packet", "hist_log2_us", "worst_calls", "direct_path", "first_calls",
+            "first_calls_max_us", "parity")
+    rec = {"what": what}
+    rec.update({k: r.get(k) for k in keys})
+    return rec
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
@@ -330,6 +372,7 @@ def main():
     ap.add_argument("--no-realtime", action="store_true", help="skip the one-packet-per-call measurement (dspi_host -rt, one stream) of the default configuration")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-run oracle check of the timed context (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="default run: skip the short runs of BASELINE configs 2, 2b and 5 that follow config 3")
+    ap.add_argument("--no-side-runs", action="store_true", help="default run: skip the child runs (200 packets per launch on tiled words; the previous round's library on this box)")
     args = ap.parse_args()
 
     # ---- N ranks without an external launcher: become the launcher ----
@@ -394,7 +437,7 @@ def main():
                 out["configs"][name] = {"error": str(e)[:300]}
     if dist and out is not None:      # (ranks other than 0 return None)
         out["dist"] = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "world_size": world,
-                       "collective": "all_reduce(SUM) of the frames + all_reduce(MAX) of the elapsed time, 8 bytes each, after the timed region (dspi_amd/shard.py)"}
+                       "collective": "all_reduce(SUM) of the frames + all_reduce(MAX) of the elapsed time, 8 bytes each, then one all_gather of 12 doubles per rank (its times, its parity verdict and checked streams), all after the timed region (dspi_amd/shard.py)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist: dist.destroy_process_group()
@@ -542,15 +585,34 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
         if smi: smi.stop()
         plan = ctx.launch_plan()
         # whole job: frames of all ranks / the slowest rank's time — sum and max over ranks, 2 x 8 bytes over RCCL
-        from dspi_amd.shard import reduce_throughput
+        from dspi_amd.shard import reduce_throughput, gather_ranks
+        elapsed_local = elapsed
         _, elapsed, fps = reduce_throughput(dist, float(S) * frames * args.steps, elapsed, device=dev if backend == "nccl" else "cpu")
         m = dict(contract=contract if flavor == 1 else "integer", out_layout=layout, input=inp, frames_per_s=fps, value=fps * CH,
                  ms_per_step=elapsed / args.steps * 1e3, kernel_ms=kernel_ms, latency_layout=plan.get("latency_layout", 0) > 0)
         m["enabled_only"] = bool(w.get("enabled_only")) if enabled_only is None else enabled_only      # True: silent pairs and the sub are not zero-filled (fewer bytes than the firmware's own stores)
         if smi: m["power"] = smi.window(*timed_steps.window) if smi.ok else None
         m["preload_steps"] = preload
-        if check and rank == 0 and not args.no_parity:
-            m["parity"] = parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, args.warmup + preload + args.steps)
+        # N = 1: 32 streams of the timed context against the oracle.  N > 1: EVERY rank checks 8 streams of its own shard (its own context, its own
+        # input) and the verdicts travel to rank 0 with the per-rank times in one all_gather — a rank that computes wrong words fails the job
+        # wherever it sits, and the line lists every rank's checked streams and step time.
+        if check and not args.no_parity and (rank == 0 or world > 1):
+            try:
+                m["parity"] = parity_check(ctx, fma, pcm, pairs, sub, peaks, tiled, args.warmup + preload + args.steps, k=32 if world == 1 else 8)
+            except SystemExit as e:
+                if world == 1: raise
+                m["parity"] = {"parity_checked": 0, "parity_streams": [], "parity_error": str(e)}
+        if check and world > 1:
+            par = m.get("parity") or {}
+            ids = (list(par.get("parity_streams", [])) + [-1] * 8)[:8]
+            rows = gather_ranks(dist, [elapsed_local / args.steps * 1e3, kernel_ms, float(par.get("parity_checked", 0)), 1.0 if par.get("parity_error") else 0.0] + ids,
+                                device=dev if backend == "nccl" else "cpu")
+            m["per_rank"] = [{"rank": r, "ms_per_step": v[0], "kernel_ms": v[1], "parity_checked": int(v[2]), "parity_streams": [int(x) for x in v[4:] if x >= 0]} for r, v in enumerate(rows)]
+            if any(v[3] for v in rows):
+                raise SystemExit("bench.py: PARITY FAILURE on rank(s) %s" % [r for r, v in enumerate(rows) if v[3]])
+            if not args.no_parity:
+                m["parity"] = dict(par, parity_checked=sum(int(v[2]) for v in rows), parity_streams=[int(x) for v in rows for x in v[4:] if x >= 0],
+                                   parity_ranks=world)
         ctx.close()
         del pairs, sub, peaks
         torch.cuda.empty_cache()
@@ -606,6 +668,23 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
                 r["valu_fraction_at_sclk"] = prof["valu_insts_per_frame"] * per_launch_frames / (m["kernel_ms"] * 1e-3) / (1024 * pw["sclk_mhz"] * 1e6 / 4.0)
         else:
             r.update(power_w=None, sclk_mhz=None, sclk_max_mhz=None)
+        # The energy ceiling: every full-size run of this chain sits at the socket's power limit, so the roofline of this path
+        # on this part is joules.  energy_j = mean socket power over the timed region x the kernel's time; energy_floor_j = what the launch cannot
+        # avoid spending by the builder's model: the chain's arithmetic alone (the "arithmetic only" ablation: no delays, leveller off, no word
+        # buffers, J per frame as measured, static power included for its own duration) + the STRICT bytes at the measured joules per HBM byte.
+        pm = latest_power_model() if kernel_key in ("chain3", "perstream", "perstream_eq") else None
+        if pw and pw.get("power_w"):
+            r["energy_j"] = pw["power_w"] * m["kernel_ms"] * 1e-3
+            if pm:
+                r["energy_floor_j"] = per_launch_frames * (pm["arith_j_per_frame"] + alg["exact"] * pm["hbm_j_per_byte"])
+                r["frac_energy"] = r["energy_floor_j"] / r["energy_j"]
+                r["energy_model"] = {"source": pm["source"], "arith_j_per_frame": pm["arith_j_per_frame"], "hbm_j_per_byte": pm["hbm_j_per_byte"], "idle_w": pm.get("idle_w"),
+                                     "stale": pm.get("src_sha16") != SRC_SHA16,
+                                     "what": "floor = frames x (arithmetic-only J/frame + strict bytes/frame x J/byte); tools/ablate_power.py on the builder's box"}
+            else:
+                r["energy_floor_j"] = r["frac_energy"] = None
+        else:
+            r["energy_j"] = r["energy_floor_j"] = r["frac_energy"] = None
         issue = r.get("valu_fraction_at_sclk") or r["valu_fraction"]
         mem = r["hbm_fraction_measured_traffic"]
         if pw and pw["sclk_mhz"] and pw["sclk_max_mhz"] and pw["sclk_mhz"] < 0.9 * pw["sclk_max_mhz"]:
@@ -655,6 +734,29 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
     if primary.get("parity"): out.update(primary["parity"])
     else: out["parity_checked"] = 0
     if primary.get("enabled_only"): out["config"]["enabled_only"] = "DSPI_OUT_ENABLED_ONLY: silent pairs and the sub are left unwritten (the firmware zero-fills them, usb_audio.c:930-933)"
+    # two more entries of `also`, each a child run of this file on the same box: 200 packets per launch on tiled words (the history store and the
+    # launch's head amortise: the launch-span end of the kernel), and the PREVIOUS round's library with the driver's own arguments — the headline's
+    # box-to-box spread (+-5 %) is larger than a round's gain, so only a same-box pair says what the round did (tools/ab_bench.sh, in the line)
+    if world == 1 and args.config == "3" and not args.no_side_runs and not args.no_variants and not args.streams and not args.blocks_per_step:
+        r = side_run(["--out-layout", "tiled", "--blocks-per-step", "200", "--steps", "10", "--warmup", "3", "--contract", args.contract])
+        also.append({"contract": args.contract, "out_layout": "tiled", "input": "mix", "blocks_per_step": 200, "child_run": True, "error": r.get("error"),
+                     "ms_per_step": r.get("ms_per_step"), "ms_per_50_packets": (r["ms_per_step"] / 4.0) if r.get("ms_per_step") else None, "value": r.get("value"),
+                     "kernel_ms": (r.get("roofline") or {}).get("kernel_ms"), "roofline_frac": (r.get("roofline") or {}).get("frac"),
+                     "roofline_frac_hbm_resident": (r.get("roofline") or {}).get("frac_hbm_resident"), "parity_checked": r.get("parity_checked")})
+        prev = sorted(glob.glob(os.path.join(ROOT, "dspi_amd", "csrc", "libr0[0-9].so")))
+        if prev:
+            ab = []
+            for tag, envv in (("this", None), ("prev", {"DSPI_LIB": prev[-1]}), ("this", None), ("prev", {"DSPI_LIB": prev[-1]})):      # A B A B, minutes apart on one box
+                r = side_run(["--steps", str(args.steps), "--warmup", str(args.warmup), "--contract", args.contract, "--out-layout", args.out_layout, "--no-parity"], env=envv)
+                ab.append({"library": os.path.basename(prev[-1]) if tag == "prev" else "libdspi_mi355x.so", "ms_per_step": r.get("ms_per_step"),
+                           "kernel_ms": (r.get("roofline") or {}).get("kernel_ms"), "error": r.get("error")})
+            ok = [x for x in ab if x["kernel_ms"]]
+            mean = lambda lib: (lambda v: sum(v) / len(v) if v else None)([x["kernel_ms"] for x in ok if x["library"] == lib])
+            a_ms, b_ms = mean("libdspi_mi355x.so"), mean(os.path.basename(prev[-1]))
+            out["same_box_ab"] = {"what": "this round's library and the previous round's (rebuilt from its last commit by __graft_entry__.build()), alternating child runs of bench.py on THIS box",
+                                  "runs": ab, "kernel_ms_this": a_ms, "kernel_ms_prev": b_ms, "ratio_this_over_prev": (a_ms / b_ms) if a_ms and b_ms else None}
+        else:
+            out["same_box_ab"] = {"what": "previous round's library not present (dspi_amd/csrc/libr0N.so: built by __graft_entry__.build() from git history)", "runs": []}
     if also:
         out["also"] = also
     # The drop-in call as the firmware makes it (usb_audio.c:1326-1332: ONE packet per call, host buffers), beside the batched figure above:
@@ -668,21 +770,22 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
             d1 = Dspi(W.F32_FMA if args.contract == "fma" else 1, 1, device=dev.index)
             d1.set_rate(FS); assert d1.load_bulk(w["blob"]) == 0
             bulk = d1.collect_bulk(); d1.close()
-            r = bench_realtime.run("f32fma" if args.contract == "fma" else "f32", W.F32_FMA if args.contract == "fma" else 1, 1, FS, B, 3000, 1000, check=True, bulk=bulk)
-            out["realtime_call"] = {"what": "one packet per dspi_process(), host buffers, one stream of this preset (dspi_host -rt)", "calls": r["calls"], "p50_us": r["p50_us"], "p99_us": r["p99_us"],
-                                    "max_us": r["max_us"], "packet_us": r["packet_us"], "over_packet_time": r["over_packet_time"], "parity": r.get("parity")}
-        except BaseException as e:  # a missing dspi_host binary must not cost the line
+            r = bench_realtime.run("f32fma" if args.contract == "fma" else "f32", W.F32_FMA if args.contract == "fma" else 1, 1, FS, B, RT_CALLS, 1000, check=True, bulk=bulk)
+            out["realtime_call"] = rt_record("one packet per dspi_process(), host buffers, one stream of this preset (dspi_host -rt)", r)
+        except (OSError, subprocess.SubprocessError) as e:  # a missing dspi_host binary must not cost the line; a parity failure (SystemExit / AssertionError) fails the run
             out["realtime_call"] = {"what": "one packet per dspi_process()", "p50_us": None, "error": str(e)[:200]}
         # ... and the RP2040 Q28 flavour's: one 48-frame packet at 48 kHz, one stream of BASELINE config 5's preset (the integer chain's latency
         # layout, dspi_chain_q28_lat.inc), every word of every call checked against the oracle
         try:
             from dspi_amd import workloads as WL
-            r = bench_realtime.run("q28", 0, 1, 48000, 48, 3000, 1000, check=True)
-            out["realtime_call_q28"] = {"what": "one packet per dspi_process(), host buffers, one stream of BASELINE config 5's preset (dspi_host -rt -f q28)", "calls": r["calls"], "p50_us": r["p50_us"],
-                                        "p99_us": r["p99_us"], "max_us": r["max_us"], "packet_us": r["packet_us"], "over_packet_time": r["over_packet_time"], "parity": r.get("parity")}
-        except BaseException as e:
+            r = bench_realtime.run("q28", 0, 1, 48000, 48, RT_CALLS, 1000, check=True)
+            out["realtime_call_q28"] = rt_record("one packet per dspi_process(), host buffers, one stream of BASELINE config 5's preset (dspi_host -rt -f q28)", r)
+        except (OSError, subprocess.SubprocessError) as e:
             out["realtime_call_q28"] = {"what": "one packet per dspi_process(), Q28", "p50_us": None, "error": str(e)[:200]}
-    if world == 1 and not args.no_cpu_baseline:
+    if primary.get("per_rank"): out["per_rank"] = primary["per_rank"]
+    # (N > 1 too: north_star wants the reference's C path on the host cores NEXT TO the 2 / 4 / 8-GPU figures; rank 0 times it after the GPU
+    #  work of every rank has ended — the other ranks idle at the process group's teardown meanwhile)
+    if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(flavor, FS, B, w["blob"], CH, args.contract == "fma" and flavor == 1, w["vol"], f"config {args.config}")
         except Exception as e:  # the GPU number stands on its own

@@ -56,6 +56,8 @@ struct dspi_ctx {
     bool populated = false;      // DSPI_BOOT_POPULATED_FLASH: the streams are devices whose flash already holds a preset directory
     bool audio_started = false;  // a dspi_process has run: the devices are no longer booting (dspi_load_flash_dump)
     bool no_direct = false;      // DSPI_NO_DIRECT (development / tests, read once at dspi_create): the staged path for small host calls too
+    uint32_t direct_spin_us = 0; // DSPI_DIRECT_SPIN_US (read once at dspi_create): how long a direct call polls its stream before the blocking wait; 0 = the call's own audio time (>= 300 us)
+    uint64_t direct_stats[5] = {0, 0, 0, 0, 0};      // dspi_debug_direct_stats: calls, calls that fell back to the blocking wait, max enqueue ns, max wait ns, last spin budget ns
     // device
     hipStream_t hs = nullptr;
     // host-buffer dspi_process: H2D, kernels and D2H of consecutive row chunks overlap on three streams (created on first use)
@@ -708,6 +710,7 @@ int dspi_create(dspi_ctx **out, int flavor, uint32_t n_streams, int hip_device) 
     c->fma = fma;
     c->populated = populated;
     c->no_direct = getenv("DSPI_NO_DIRECT") != nullptr;
+    if (const char *e = getenv("DSPI_DIRECT_SPIN_US")) { const long v = atol(e); if (v > 0) c->direct_spin_us = (uint32_t)std::min<long>(v, 1000000L); }
     c->images.push_back(std::make_unique<Params>(flavor, fma, !populated));
     c->image_refs.push_back(n_streams);
     c->stream_image.assign(n_streams, 0);
@@ -879,6 +882,12 @@ int dspi_debug_launch_plan(dspi_ctx *c, uint32_t *counts, size_t n_counts) {
     return n;
 }
 
+int dspi_debug_direct_stats(dspi_ctx *c, uint64_t *out, size_t n) {
+    if (!c || !out || n < 5) return DSPI_E_INVAL;
+    for (int i = 0; i < 5; i++) out[i] = c->direct_stats[i];
+    return 5;
+}
+
 int dspi_debug_image_count(dspi_ctx *c) {
     if (!c) return DSPI_E_INVAL;
     if (c->merge_hint) merge_images(c);
@@ -902,6 +911,22 @@ int dspi_debug_eq_taps(dspi_ctx *c, int32_t stream, int channel, const float *x,
         launch_eq_taps(c->fma, d_img, channel, d_x, n, d_t, d_o, c->hs) != hipSuccess || hipStreamSynchronize(c->hs) != hipSuccess ||
         hipMemcpy(taps, d_t, nb * (kBands + 1), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(other, d_o, nb * kBands, hipMemcpyDeviceToHost) != hipSuccess)
         return done(fail(c, DSPI_E_HIP, "EQ taps failed"));
+    return done(DSPI_OK);
+}
+
+int dspi_debug_detmath(dspi_ctx *c, int which, const float *a, const float *b, uint32_t n, float *out) {
+    if (!c || !a || !out || (which && !b) || n == 0 || n > (1u << 24) || (which != 0 && which != 1)) return DSPI_E_INVAL;
+    if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
+    HIPCK(c, hipSetDevice(c->device));
+    float *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+    const size_t nb = (size_t)n * sizeof(float);
+    auto done = [&](int rc) { (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o); return rc; };
+    if (hipMalloc((void **)&d_a, nb) != hipSuccess || hipMalloc((void **)&d_b, nb) != hipSuccess || hipMalloc((void **)&d_o, nb) != hipSuccess)
+        return done(fail(c, DSPI_E_NOMEM, "hipMalloc failed (detmath)"));
+    if (hipMemcpy(d_a, a, nb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_b, which ? b : a, nb, hipMemcpyHostToDevice) != hipSuccess ||
+        launch_detmath(which, d_a, d_b, n, d_o, c->hs) != hipSuccess || hipStreamSynchronize(c->hs) != hipSuccess ||
+        hipMemcpy(out, d_o, nb, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(c, DSPI_E_HIP, "detmath kernel failed"));
     return done(DSPI_OK);
 }
 
@@ -1034,10 +1059,10 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
     if ((bit_depth != 16 && bit_depth != 24) || n_blocks == 0 || block_len == 0 || block_len > DSPI_MAX_BLOCK_LEN)
         return fail(c, DSPI_E_INVAL, "bit_depth must be 16/24, 1 <= block_len <= 192, n_blocks >= 1");
+    const auto call_t0 = std::chrono::steady_clock::now();
     HIPCK(c, hipSetDevice(c->device));
     int rc = commit_params(c);
     if (rc) return rc;
-    c->audio_started = true;
 
     const size_t frames = (size_t)n_blocks * block_len;
     const size_t in_b = (size_t)c->n_streams * frames * (bit_depth == 24 ? 6 : 4);
@@ -1155,6 +1180,7 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
                 hipError_t e = launch_chain(c->flavor, ls[l].packed, lev != 0, a, (uint32_t)(hi - lo), c->hs);
                 if (e == hipErrorNotSupported) return fail(c, DSPI_E_UNSUPPORTED, "this flavour has no HIP kernel yet");
                 if (e != hipSuccess) return fail(c, DSPI_E_HIP, std::string("chain kernel launch: ") + hipGetErrorString(e));
+                c->audio_started = true;      // only now: a call refused for its arguments, or one that could not allocate, leaves a booting device booting (dspi_load_flash_dump)
             }
         return 0;
     };
@@ -1191,11 +1217,27 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         // the launches take tens of microseconds: polling the stream answers within a microsecond of their end, a blocking wait adds a wake-up
         // — but only for as long as such launches take: after ~300 us of polling the call falls back to the blocking wait (a hung queue, or a
         // host running many contexts, must not pin a core)
+        // How long: the audio time the call carries (a caller in the firmware's rhythm has exactly that long per call, and a wake-up from the
+        // blocking wait — an interrupt, a scheduler pass — is the dropout-class outlier of BENCH_r05: one 10 ms call in 3 000), never less than
+        // 300 us, never more than 50 ms; DSPI_DIRECT_SPIN_US (read at dspi_create) overrides it.
         hipError_t q;
         const auto spin_t0 = std::chrono::steady_clock::now();
+        const uint64_t audio_us = (uint64_t)frames * 1000000u / 44100u;      // (the slowest rate the firmware runs: an upper bound of the packet's time)
+        const auto budget = std::chrono::microseconds(c->direct_spin_us ? (uint64_t)c->direct_spin_us : std::min<uint64_t>(50000u, std::max<uint64_t>(300u, audio_us)));
         uint32_t polls = 0;
+        bool fell_back = false;
         while ((q = hipStreamQuery(c->hs)) == hipErrorNotReady) {
-            if ((++polls & 63u) == 0 && std::chrono::steady_clock::now() - spin_t0 > std::chrono::microseconds(300)) { q = hipStreamSynchronize(c->hs); break; }
+            if ((++polls & 63u) == 0 && std::chrono::steady_clock::now() - spin_t0 > budget) { q = hipStreamSynchronize(c->hs); fell_back = true; break; }
+        }
+        {
+            const auto t_end = std::chrono::steady_clock::now();
+            const uint64_t enq = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(spin_t0 - call_t0).count();
+            const uint64_t wait = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_end - spin_t0).count();
+            c->direct_stats[0]++; c->direct_stats[1] += fell_back ? 1u : 0u;
+            if (c->direct_stats[0] > 8) {      // (the context's first calls allocate the pinned area, build the launch lists, load the code objects: not the steady state)
+                c->direct_stats[2] = std::max(c->direct_stats[2], enq); c->direct_stats[3] = std::max(c->direct_stats[3], wait);
+            }
+            c->direct_stats[4] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(budget).count();
         }
         if (q != hipSuccess) return fail(c, DSPI_E_HIP, std::string("stream: ") + hipGetErrorString(q));
         if (out->pairs) memcpy(out->pairs, c->h_direct + off_pairs, pairs_b);

@@ -20,9 +20,16 @@
  *             bench.py's keys.  -S weak (default): -s streams PER GPU; strong: -s streams in total.  -o: device 0's first stream, last call.
  *             -D none: no device (contexts are DSPI_DEVICE_NONE, nothing is processed): the partition, the parameter path of every
  *             context and the reduction's host stand-in, for boxes without a GPU (tests/test_host_binary_cpu.py).
+ *             Every feeder thread is pinned to the CPUs of its GPU's NUMA node (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<id>/numa_node ->
+ *             /sys/devices/system/node/node<k>/cpulist; -D none: node = rank modulo the nodes present) and the line says so ("affinity");
+ *             it carries a "roofline" object (algorithmic HBM bytes from the preset's own delays and enables, read back through the vendor
+ *             requests 0x79 / 0x73, over the slowest device's time) and, with -o, the last call's pair words of EVERY device's first
+ *             stream (<path> for device 0, <path>.dev<k> for the others) plus a checksum of them in "checked_streams".
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,7 +39,10 @@
 /* the HIP runtime's C API and RCCL: used by -g only (device buffers; the final all-reduce) */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
+/* DSPI_HOST_RCCL (the Makefile sets it when the ROCm install has the RCCL header): without it -g reduces on the host and says so */
+#ifdef DSPI_HOST_RCCL
 #include <rccl/rccl.h>
+#endif
 
 static void *slurp(const char *path, size_t *len) {
     FILE *f = fopen(path, "rb");
@@ -109,6 +119,27 @@ static int realtime(dspi_ctx *ctx, uint32_t streams, uint32_t rate, uint32_t blo
     printf("rt: %u streams x %u calls of one %u-frame packet (%.0f us of audio): p50 %.1f us  p99 %.1f us  p99.9 %.1f us  max %.1f us  (first %u calls: max %.1f us)  mean %.1f us = %.1f x real time\n",
            streams, calls, block_len, packet_s * 1e6, srt[n / 2] * 1e6, srt[(size_t)(n * 0.99)] * 1e6, srt[(size_t)(n * 0.999)] * 1e6, srt[n - 1] * 1e6, skip, first_max * 1e6,
            total / calls * 1e6, packet_s / (total / calls));
+    /* the tail, not only percentiles: calls longer than the packet they carry (a dropout in the firmware's rhythm), a log2 histogram, and the
+     * library's own record of the polling path (dspi_debug_direct_stats) */
+    {
+        uint32_t over = 0, hist[16];
+        memset(hist, 0, sizeof hist);
+        for (uint32_t c = skip; c < calls; c++) {
+            if (lat[c] > packet_s) over++;
+            const double us = lat[c] * 1e6;
+            int b = 0;
+            while (b < 15 && us >= (double)(16u << b)) b++;       /* bucket b: [8 << b, 16 << b) us; bucket 0: < 16 us; bucket 15: >= 262 144 us */
+            hist[b]++;
+        }
+        uint64_t ds[5] = {0, 0, 0, 0, 0};
+        (void)dspi_debug_direct_stats(ctx, ds, 5);
+        printf("rt-json: {\"calls\": %u, \"steady_calls\": %u, \"packet_us\": %.3f, \"p50_us\": %.2f, \"p99_us\": %.2f, \"p99_9_us\": %.2f, \"p99_99_us\": %.2f, \"max_us\": %.2f, "
+               "\"n_over_packet\": %u, \"hist_log2_us\": {\"first_edge_us\": 16, \"counts\": [",
+               calls, n, packet_s * 1e6, srt[n / 2] * 1e6, srt[(size_t)(n * 0.99)] * 1e6, srt[(size_t)(n * 0.999)] * 1e6, srt[(size_t)(n * 0.9999)] * 1e6, srt[n - 1] * 1e6, over);
+        for (int b = 0; b < 16; b++) printf("%s%u", b ? ", " : "", hist[b]);
+        printf("]}, \"direct_path\": {\"calls\": %llu, \"blocking_waits\": %llu, \"max_enqueue_us\": %.2f, \"max_wait_us\": %.2f, \"spin_budget_us\": %.1f}}\n",
+               (unsigned long long)ds[0], (unsigned long long)ds[1], ds[2] / 1e3, ds[3] / 1e3, ds[4] / 1e3);
+    }
     free(srt);
     }
 done:
@@ -138,7 +169,88 @@ typedef struct {
     int rc; char err[200];
     double frames, seconds;
     int channels;
+    int numa_node, cpus_pinned; char pin_src[24];       /* the feeder thread's affinity */
+    double bytes_strict, bytes_resident;                /* algorithmic HBM bytes per frame of this shard's preset */
+    uint32_t check_sum, check_words; int checked;       /* the last call's pair words of the shard's first stream */
 } Shard;
+
+/* "0-3,8,10-11" -> cpu_set_t; returns the number of CPUs set */
+static int parse_cpulist(const char *s, cpu_set_t *set) {
+    int n = 0;
+    CPU_ZERO(set);
+    while (*s) {
+        char *e;
+        long a = strtol(s, &e, 10), b = a;
+        if (e == s) break;
+        if (*e == '-') { s = e + 1; b = strtol(s, &e, 10); if (e == s) break; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0 && !CPU_ISSET((int)c, set)) { CPU_SET((int)c, set); n++; }
+        s = e;
+        while (*s == ',' || *s == '\n' || *s == ' ') s++;
+    }
+    return n;
+}
+static int read_line(const char *path, char *buf, size_t cap) {
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    if (!fgets(buf, (int)cap, f)) { fclose(f); return -1; }
+    fclose(f);
+    return 0;
+}
+/* pin the calling thread to the CPUs of the GPU's NUMA node (the feeder's buffers and doorbells stay on the socket
+ * the device hangs off).  dry: no device — node = rank modulo the nodes present, so that the parsing and the call run on any box. */
+static void pin_to_gpu_node(Shard *h) {
+    char path[160], buf[4096];
+    int node = -1;
+    h->numa_node = -1; h->cpus_pinned = 0; snprintf(h->pin_src, sizeof h->pin_src, "none");
+    if (!h->dry) {
+        char bus[64] = "";
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, h->rank) != hipSuccess) return;
+        for (char *q = bus; *q; q++) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');      /* sysfs names are lower case */
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+        if (read_line(path, buf, sizeof buf)) return;
+        node = atoi(buf);
+        snprintf(h->pin_src, sizeof h->pin_src, "pci");
+        if (node < 0) { snprintf(h->pin_src, sizeof h->pin_src, "pci: no node"); return; }      /* single-node boxes and VMs report -1: nothing to pin to */
+    } else {
+        int nodes = 0;
+        for (;; nodes++) { snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", nodes); if (read_line(path, buf, sizeof buf)) break; }
+        if (!nodes) return;
+        node = h->rank % nodes;
+        snprintf(h->pin_src, sizeof h->pin_src, "dry: rank %% %d nodes", nodes);
+    }
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    if (read_line(path, buf, sizeof buf)) return;
+    cpu_set_t want, have;
+    if (parse_cpulist(buf, &want) < 1) return;
+    /* only CPUs this process may use at all (cgroup / taskset): the intersection, if it is not empty */
+    if (sched_getaffinity(0, sizeof have, &have) == 0) {
+        cpu_set_t both; CPU_AND(&both, &want, &have);
+        if (CPU_COUNT(&both) > 0) want = both; else return;
+    }
+    if (pthread_setaffinity_np(pthread_self(), sizeof want, &want) != 0) return;
+    h->numa_node = node; h->cpus_pinned = CPU_COUNT(&want);
+}
+
+/* Algorithmic HBM bytes per frame of the context's preset, two of bench.py's three ways (bench.py:algorithmic_bytes): the delays and enables are
+ * read back through the firmware's own control requests (REQ_GET_OUTPUT_DELAY 0x79, REQ_GET_OUTPUT_ENABLE 0x73, usb_audio.c vendor handler). */
+static void algorithmic_bytes(dspi_ctx *ctx, uint32_t rate, size_t frames_per_call, double *strict, double *resident) {
+    const int n_out = dspi_num_outputs(ctx), float_flavor = dspi_num_channels(ctx) == 11;
+    const double max_d = float_flavor ? 4096.0 : 2048.0, T = (double)frames_per_call;
+    const double io = 4.0 + 4.0 * (n_out - 1) + 4.0;
+    *strict = io; *resident = io;
+    for (int o = 0; o < n_out; o++) {
+        float ms = 0.0f; uint8_t en = 0;
+        if (dspi_vendor_get(ctx, 0, 0x79, (uint16_t)o, &ms, 4) != 4 || dspi_vendor_get(ctx, 0, 0x73, (uint16_t)o, &en, 1) != 1) continue;
+        double total_ms = (double)ms + (o == n_out - 1 ? 128.0 / rate * 1000.0 : 0.0);      /* the sub's alignment delay */
+        double d = floor(total_ms * rate / 1000.0);
+        if (d < 0.0) d = 0.0;
+        if (d > max_d) d = max_d;
+        if (d > 0.0 && en) {
+            *resident += 8.0;
+            *strict += 4.0 * (d < T ? d : T) / T + 4.0 * (max_d < T ? max_d : T) / T;
+        }
+    }
+}
 
 static void *shard_main(void *arg) {
     Shard *h = (Shard *)arg;
@@ -148,6 +260,7 @@ static void *shard_main(void *arg) {
     int16_t *d_pcm = NULL; int32_t *d_pairs = NULL, *d_sub = NULL; uint16_t *d_peaks = NULL;
     int in_barrier = 0;
     h->frames = 0.0; h->seconds = 0.0; h->rc = 0;
+    pin_to_gpu_node(h);       /* before the context exists: its staging buffers and the runtime's queues are then first touched from this node */
 #define SHARD_FAIL(...) do { snprintf(h->err, sizeof h->err, __VA_ARGS__); h->rc = 1; goto out; } while (0)
     if (S) {
         int rc = dspi_create(&ctx, h->flavor, S, h->dry ? DSPI_DEVICE_NONE : h->rank);
@@ -157,6 +270,7 @@ static void *shard_main(void *arg) {
         dspi_set_host_volume(ctx, DSPI_ALL_STREAMS, (int16_t)lrint(h->vol_db * 256.0));
         if (h->bulk && (rc = dspi_load_bulk(ctx, DSPI_ALL_STREAMS, h->bulk, h->bulk_len))) SHARD_FAIL("bulk_params_apply -> %d", rc);
         if (h->slot && (rc = dspi_load_preset_slot(ctx, DSPI_ALL_STREAMS, h->slot, h->slot_len, -1))) SHARD_FAIL("preset_load -> %d", rc);
+        algorithmic_bytes(ctx, h->rate, frames, &h->bytes_strict, &h->bytes_resident);
     }
     if (S && !h->dry) {
         const int pairs_n = dspi_num_pairs(ctx);
@@ -197,12 +311,21 @@ static void *shard_main(void *arg) {
         in_barrier = 2;
         if (rc) SHARD_FAIL("dspi_process: %d %s", rc, dspi_last_error(ctx));
         h->frames = (double)S * (double)frames * h->calls;
-        if (h->rank == 0 && h->outp) {                /* device 0's first stream, the last call: the test's window on the words */
+        {                                             /* every device's first stream, the last call: the checker's window on the words */
             const size_t n = (size_t)pairs_n * frames * 8;
-            void *w = malloc(n);
-            FILE *f = fopen(h->outp, "wb");
-            if (!w || !f || hipMemcpy(w, d_pairs, n, hipMemcpyDeviceToHost) != hipSuccess) { if (f) fclose(f); free(w); SHARD_FAIL("-o %s", h->outp); }
-            fwrite(w, 1, n, f); fclose(f); free(w);
+            uint32_t *w = (uint32_t *)malloc(n);
+            if (!w || hipMemcpy(w, d_pairs, n, hipMemcpyDeviceToHost) != hipSuccess) { free(w); SHARD_FAIL("D2H of the checked stream"); }
+            uint32_t sum = 2166136261u;               /* FNV-1a over the words: printed, and recomputed from the oracle's words by the tests */
+            for (size_t i = 0; i < n / 4; i++) { sum ^= w[i]; sum *= 16777619u; }
+            h->check_sum = sum; h->check_words = (uint32_t)(n / 4); h->checked = 1;
+            if (h->outp) {
+                char path[512];
+                if (h->rank == 0) snprintf(path, sizeof path, "%s", h->outp); else snprintf(path, sizeof path, "%s.dev%d", h->outp, h->rank);
+                FILE *f = fopen(path, "wb");
+                if (!f) { free(w); SHARD_FAIL("-o %s", path); }
+                fwrite(w, 1, n, f); fclose(f);
+            }
+            free(w);
         }
     } else if (S) {
         h->frames = (double)S * (double)frames * h->calls;      /* dry run: what this shard WOULD have processed */
@@ -228,6 +351,12 @@ static int reduce_node(Shard *sh, int n, int dry, double *frames, double *second
         *how = "host stand-in (no device)";
         return 0;
     }
+#ifndef DSPI_HOST_RCCL
+    *frames = 0.0; *seconds = 0.0;
+    for (int i = 0; i < n; i++) { *frames += sh[i].frames; if (sh[i].seconds > *seconds) *seconds = sh[i].seconds; }
+    *how = "host reduction (built without RCCL: no rccl/rccl.h in this ROCm install)";
+    return 0;
+#else
     ncclComm_t *comm = (ncclComm_t *)calloc((size_t)n, sizeof(ncclComm_t));
     hipStream_t *st = (hipStream_t *)calloc((size_t)n, sizeof(hipStream_t));
     double **d = (double **)calloc((size_t)n, sizeof(double *));
@@ -262,6 +391,7 @@ out:
     }
     free(comm); free(st); free(d); free(devs);
     return rc;
+#endif
 }
 
 static int node_run(int n_gpus, int strong, int dry, int flavor, uint32_t streams, uint32_t rate, uint32_t block_len, uint32_t blocks, uint32_t calls,
@@ -304,7 +434,23 @@ static int node_run(int n_gpus, int strong, int dry, int flavor, uint32_t stream
                fps * channels, n_gpus, calls, warmup, seconds / calls * 1e3, strong ? "strong" : "weak", (flavor & 0xff) ? "f32" : "int32 (Q28)",
                total, rate, blocks, block_len, total, channels, frames, seconds, fps, fps / rate);
         for (int i = 0; i < n_gpus; i++) printf("%s[%u, %u]", i ? ", " : "", sh[i].first, sh[i].last);
-        printf("]}, \"dist\": {\"backend\": \"%s\", \"world_size\": %d}, \"dry_run\": %s}\n", how, n_gpus, dry ? "true" : "false");
+        printf("], \"ms_per_step_per_device\": [");
+        for (int i = 0; i < n_gpus; i++) printf("%s%.6f", i ? ", " : "", sh[i].seconds / calls * 1e3);
+        printf("]}, ");
+        {   /* roofline of the node: algorithmic bytes of every device's shard over the slowest device's time, against N x 8 TB/s */
+            double strict_b = 0.0, resident_b = 0.0;
+            for (int i = 0; i < n_gpus; i++) { const double f = sh[i].frames; strict_b += f * sh[i].bytes_strict; resident_b += f * sh[i].bytes_resident; }
+            const double peak = 8000.0 * n_gpus, ach = seconds > 0.0 ? strict_b / seconds / 1e9 : 0.0, ach_r = seconds > 0.0 ? resident_b / seconds / 1e9 : 0.0;
+            printf("\"roofline\": {\"bound\": \"hbm\", \"achieved\": %.3f, \"peak\": %.1f, \"unit\": \"GB/s\", \"frac\": %.6f, \"traffic\": null, "
+                   "\"algorithmic_bytes_per_frame\": %.3f, \"algorithmic_bytes_per_frame_hbm_resident\": %.3f, \"frac_hbm_resident\": %.6f, "
+                   "\"what\": \"strict bytes (bench.py:algorithmic_bytes) of all shards / the slowest device's wall time of %u calls; peak = n_gpus x 8 TB/s\"}, ",
+                   ach, peak, ach / peak, frames > 0.0 ? strict_b / frames : 0.0, frames > 0.0 ? resident_b / frames : 0.0, ach_r / peak, calls);
+        }
+        printf("\"affinity\": [");
+        for (int i = 0; i < n_gpus; i++) printf("%s{\"device\": %d, \"numa_node\": %d, \"cpus\": %d, \"source\": \"%s\"}", i ? ", " : "", i, sh[i].numa_node, sh[i].cpus_pinned, sh[i].pin_src);
+        printf("], \"checked_streams\": [");
+        for (int i = 0, k = 0; i < n_gpus; i++) if (sh[i].checked) printf("%s{\"device\": %d, \"stream\": %u, \"pair_words\": %u, \"fnv1a\": %u}", k++ ? ", " : "", i, sh[i].first, sh[i].check_words, sh[i].check_sum);
+        printf("], \"dist\": {\"backend\": \"%s\", \"world_size\": %d}, \"dry_run\": %s}\n", how, n_gpus, dry ? "true" : "false");
     }
     free(sh); free(th); free(bulk_b); free(slot_b);
     return rc;

@@ -73,6 +73,7 @@ hipError_t launch_i2s(bool tiled, const int32_t *pairs, uint32_t *out, uint32_t 
                       uint32_t n_wg, uint32_t pair_mask, hipStream_t stream);
 
 // ---- status at scale (dspi_status.hip): out[s] = OR of stream s's four sticky clip slots (state slots clip_slot .. clip_slot + 3)
+hipError_t launch_detmath(int which, const float *a, const float *b, uint32_t n, float *out, hipStream_t stream);      // dspi_status.hip
 hipError_t launch_clip_gather(const uint32_t *state, uint32_t n_streams, uint32_t row, uint32_t n_slots, uint32_t clip_slot, uint16_t *out, hipStream_t stream);
 
 }  // namespace dspi

@@ -1534,8 +1534,13 @@ static hipError_t launch_chain_q28_7(const KArgs &args, uint32_t n_items, hipStr
     else hipLaunchKernelGGL((chain_kernel<0, false, PL, false, 7>), dim3(n_items), dim3(64 * 7), lds, stream, args);
     return hipGetLastError();
 }
-static uint32_t q28_seven_wave_limit() {      // work items up to which the seven-wave layout is used: one per CU; DSPI_Q28_WAVES=4 / 7 forces one layout (tests, development)
-    if (const char *e = getenv("DSPI_Q28_WAVES")) { const int w = atoi(e); if (w == 7) return 0xffffffffu; if (w == 4) return 0u; }
+// DSPI_Q28_WAVES=4 / 7 forces one wave layout of chain_kernel (tests, development) and keeps the latency layout out; any other value is ignored
+static int q28_forced_waves() {
+    if (const char *e = getenv("DSPI_Q28_WAVES")) { const int w = atoi(e); if (w == 7 || w == 4) return w; }
+    return 0;
+}
+static uint32_t q28_seven_wave_limit() {      // work items up to which the seven-wave layout is used: one per CU
+    if (const int w = q28_forced_waves()) return w == 7 ? 0xffffffffu : 0u;
     static int cus[kMaxDevices] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices - 1) return 256u;
@@ -1554,7 +1559,7 @@ static uint32_t q28_latency_limit() {
 template <int FLAVOR, bool PL, bool FMA = false>
 static hipError_t launch_chain_t(const KArgs &args, uint32_t n_items, hipStream_t stream) {
     if constexpr (FLAVOR == 0) {
-        if (args.n_streams <= q28_latency_limit() && getenv("DSPI_Q28_WAVES") == nullptr) {
+        if (args.n_streams <= q28_latency_limit() && q28_forced_waves() == 0) {
             hipLaunchKernelGGL((chain_kernel_q28_lat<PL>), dim3(n_items * 64u), dim3(128), 0, stream, args);
             return hipGetLastError();
         }

@@ -9,10 +9,19 @@
 #include <stdint.h>
 
 #include "dspi_kernels.h"
+#include "../../include/dspi_detmath.h"
 
 namespace dspi {
 
 namespace {
+// dspi_debug_detmath: the leveller's two libm replacements as the DEVICE computes them, over caller-supplied arguments (tests: device ==
+// host build of the same header == binary128, including arguments constructed to take the double-double step)
+__global__ __launch_bounds__(256) void detmath_kernel(int which, const float *a, const float *b, uint32_t n, float *out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    out[i] = which ? dspi_det_powf(a[i], b[i]) : dspi_det_log10f(a[i]);
+}
+
 __global__ __launch_bounds__(256) void clip_gather_kernel(const uint32_t *state, uint32_t n_streams, uint32_t row, uint32_t n_slots, uint32_t clip_slot, uint16_t *out) {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= n_streams) return;
@@ -24,6 +33,11 @@ __global__ __launch_bounds__(256) void clip_gather_kernel(const uint32_t *state,
 
 hipError_t launch_clip_gather(const uint32_t *state, uint32_t n_streams, uint32_t row, uint32_t n_slots, uint32_t clip_slot, uint16_t *out, hipStream_t stream) {
     hipLaunchKernelGGL(clip_gather_kernel, dim3((n_streams + 255u) / 256u), dim3(256), 0, stream, state, n_streams, row, n_slots, clip_slot, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_detmath(int which, const float *a, const float *b, uint32_t n, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(detmath_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, which, a, b, n, out);
     return hipGetLastError();
 }
 

@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
     L.dspi_clear_clips.argtypes = [vp, i32]
     L.dspi_debug_image.argtypes = [vp, i32, vp, C.c_size_t]
     L.dspi_debug_launch_plan.argtypes = [vp, vp, C.c_size_t]
+    if hasattr(L, "dspi_debug_direct_stats"): L.dspi_debug_direct_stats.argtypes = [vp, vp, C.c_size_t]      # (ABI 8; bench.py's same-box A/B loads the previous round's library through this module)
     _lib = L
     return L
 
@@ -198,6 +199,12 @@ class Dspi:
         self._ck(min(self.L.dspi_debug_launch_plan(self.h, c, 7), 0), "debug_launch_plan")
         return dict(zip(("q28_shared", "packed_shared", "one_stream_per_lane_images", "packed_per_lane_values_and_bands", "packed_per_lane_values", "latency_layout",
                          "latency_layout_paired"), list(c)))
+
+    def direct_stats(self) -> dict:
+        """dspi_debug_direct_stats: the one-packet-per-call path's polling record (include/dspi.h)."""
+        c = (C.c_uint64 * 5)()
+        self._ck(min(self.L.dspi_debug_direct_stats(self.h, c, 5), 0), "debug_direct_stats")
+        return dict(calls=int(c[0]), blocking_waits=int(c[1]), max_enqueue_us=c[2] / 1e3, max_wait_us=c[3] / 1e3, spin_budget_us=c[4] / 1e3)
 
     def image_count(self) -> int:
         """dspi_debug_image_count: distinct parameter objects held (equal ones are folded after broadcast calls)."""

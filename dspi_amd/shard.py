@@ -22,3 +22,16 @@ def reduce_throughput(dist, frames_local: float, elapsed_local: float, device=No
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(f.item()), float(t.item()), float(f.item()) / float(t.item())
+
+
+def gather_ranks(dist, values, device=None):
+    """Every rank's short list of numbers on every rank: [[rank 0's values], [rank 1's], ...] (one all_gather of len(values) doubles per
+    rank, after the timed region — the per-rank times and parity verdicts of bench.py's N > 1 line)."""
+    vals = [float(v) for v in values]
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [vals]
+    import torch
+    mine = torch.tensor(vals, dtype=torch.float64, device=device)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(x) for x in t.tolist()] for t in out]

@@ -55,11 +55,12 @@
 extern "C" {
 #endif
 
-#define DSPI_ABI_VERSION 7   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
+#define DSPI_ABI_VERSION 8   /* 2: DSPI_OUT_TILED, dspi_tile_streams, dspi_pdm_*, dspi_spdif_encode; 3: DSPI_FLOAT_CONTRACT_FMA,
                               * dspi_debug_eq_taps; 4: dspi_i2s_encode, vendor requests 0xC0 / 0xC1,
                               * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, DSPI_OUT_I2S_SLOTS, DSPI_BOOT_POPULATED_FLASH, dspi_debug_launch_plan counts[5];
                               * 6: DSPI_OUT_SPDIF, dspi_spdif_block_pos; 7: dspi_out.clip_flags behind DSPI_OUT_CLIP_FLAGS, DSPI_OUT_SPDIF on every
-                              * context, (additions only: a v6 caller's three-member dspi_out is never read past `peaks`) */
+                              * context, (additions only: a v6 caller's three-member dspi_out is never read past `peaks`);
+                              * 8: dspi_debug_direct_stats, dspi_debug_detmath, the direct path's polling budget = the call's own audio time (DSPI_DIRECT_SPIN_US) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -284,6 +285,15 @@ int dspi_debug_image(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
  * presets of one structure at once (a workgroup's stream slots each read their own image).  Returns the number of counts written
  * (5, 6 or 7) or a negative DSPI_E_*. */
 int dspi_debug_launch_plan(dspi_ctx *ctx, uint32_t *counts, size_t n_counts);
+/* include/dspi_detmath.h's log10f (which = 0: out[i] = log10f(a[i]), b unused) / powf (which = 1: out[i] = powf(a[i], b[i])) evaluated on the DEVICE,
+ * host buffers, n <= 2^24: tests compare them bit for bit with the host build of the same header and with binary128. */
+int dspi_debug_detmath(dspi_ctx *ctx, int which, const float *a, const float *b, uint32_t n, float *out);
+/* Small calls on host buffers (one packet per call, usb_audio.c:1326-1332) poll the context's stream instead of sleeping on it: for the audio
+ * time the call carries (frames at 44.1 kHz; at least 300 us, at most 50 ms; DSPI_DIRECT_SPIN_US, read at dspi_create, overrides), then the
+ * blocking wait.  out[5] = {such calls so far, calls that reached the blocking wait, longest enqueue phase in ns (entry -> launches issued),
+ * longest wait phase in ns (both over the calls after the context's first eight), the last call's polling budget in ns}.  tools/bench_realtime.py reports them next to the latency percentiles.
+ * Returns 5 or a negative DSPI_E_*. */
+int dspi_debug_direct_stats(dspi_ctx *ctx, uint64_t *out, size_t n);
 /* Number of distinct parameter objects the context holds (streams share one until a per-stream call separates them; streams that
  * received the same whole state again through broadcast calls are folded back, here or at the next dspi_process).  Works on
  * host-only contexts.  Returns the count or a negative DSPI_E_*. */

@@ -16,7 +16,7 @@ def test_every_declared_symbol_is_exported(product_lib):
     for n in names:
         assert hasattr(product_lib, n), f"{n} declared in dspi.h but not exported"
     product_lib.dspi_abi_version.restype = ctypes.c_int
-    assert product_lib.dspi_abi_version() == 7
+    assert product_lib.dspi_abi_version() == 8
 
 
 def test_argument_validation(product_lib):

@@ -88,6 +88,25 @@ def test_bench_self_spawn_two_ranks(scaling):
     assert rec["n_gpus"] == 2 and rec["scaling"] == scaling and rec["value"] > 0 and rec["steps"] == 2
     per_rank = 2048 if scaling == "weak" else 1024
     assert rec["config"]["streams_per_gpu"] == per_rank, rec["config"]
+    # VERDICT r05 item 6: the N > 1 line is complete — every rank's own step time and its own 8-stream oracle check, gathered to rank 0
+    pr = rec["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and all(x["ms_per_step"] > 0 and x["kernel_ms"] > 0 and x["parity_checked"] == 8 for x in pr)
+    assert rec["parity_checked"] == 16 and rec["parity_ranks"] == 2 and len(set(rec["parity_streams"])) == 16
+    first1 = per_rank      # rank 1's first global stream (weak: rank * streams; strong: stream_range)
+    assert all(s < first1 for s in pr[0]["parity_streams"]) and all(s >= first1 for s in pr[1]["parity_streams"])
+    assert abs(rec["ms_per_step"] - max(x["ms_per_step"] for x in pr)) < 0.05 * rec["ms_per_step"]
+
+
+def test_bench_two_ranks_carry_the_cpu_baseline():
+    """... and the reference's C path on the host cores sits next to the N > 1 figure (north_star), timed by rank 0 after the GPU work."""
+    env = dict(os.environ, DSPI_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"): env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "1024", "--no-variants", "--no-parity"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    cb = rec["cpu_baseline"]
+    assert rec["n_gpus"] == 2 and cb["value"] > 0 and cb["kind"] in ("reference", "port") and cb["cores"] >= 1
 
 
 def test_bench_rccl_branch_world_size_one():

@@ -13,7 +13,8 @@ from dspi_amd import wire as W, workloads as WL
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="no GPU")]
 
-HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dspi_amd", "csrc", "dspi_host")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "dspi_amd", "csrc", "dspi_host")
 
 
 @pytest.mark.parametrize("flavor,load", [(1, "slot"), (1, "bulk"), (W.F32_FMA, "slot"), (0, "slot")])
@@ -84,3 +85,30 @@ def test_dspi_host_node_mode_through_rccl(tmp_path, flavor, scaling):
         pairs, _, _, _ = o.process(pcm, blocks, B)
     got = np.frombuffer((tmp_path / "pairs.raw").read_bytes(), dtype=np.int32).reshape(pairs.shape)
     assert np.array_equal(got, pairs)
+    # the line's own window on the words: a checksum per device over its first stream's pair words (FNV-1a), recomputed here from the ORACLE's words
+    cs = d["checked_streams"]
+    assert len(cs) == 1 and cs[0]["device"] == 0 and cs[0]["stream"] == 0 and cs[0]["pair_words"] == pairs.size
+    h = 2166136261
+    for w in pairs.astype(np.int32).view(np.uint32).reshape(-1).tolist(): h = ((h ^ w) * 16777619) & 0xFFFFFFFF
+    assert cs[0]["fnv1a"] == h
+    roof = d["roofline"]
+    assert roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and roof["achieved"] > 0
+    assert len(d["affinity"]) == 1 and d["affinity"][0]["source"].startswith("pci")
+
+
+def test_one_packet_calls_have_no_dropout_class_outliers(tmp_path):
+    """the driver's run saw one 10 ms call among 3 000 one-packet calls.  10 000 calls per flavour, steady state: no call may
+    take longer than 500 us (the packet carries 1 000 us of audio), and none may have reached the blocking wait.  One retry: the box is shared
+    with nothing, but an interrupt storm is not this library's to fix — two failures in a row are."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_realtime
+    for fname, flavor, fs, B in (("f32fma", W.F32_FMA, 96000, 96), ("q28", 0, 48000, 48)):
+        worst = None
+        for attempt in range(2):
+            r = bench_realtime.run(fname, flavor, 1, fs, B, 10000, 1000, check=(attempt == 0))
+            worst = r
+            if r["max_us"] <= 500.0 and r["n_over_packet"] == 0: break
+        assert worst["max_us"] <= 500.0 and worst["n_over_packet"] == 0, worst
+        assert worst["direct_path"]["calls"] == 10000 and worst["direct_path"]["blocking_waits"] == 0, worst["direct_path"]
+        assert sum(worst["hist_log2_us"]["counts"]) == worst["calls"] - worst["first_calls"]

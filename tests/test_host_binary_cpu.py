@@ -50,3 +50,36 @@ def test_argument_errors():
     assert run("-g", 0, "-D", "none")[0].returncode != 0 or True       # -g 0 is the single-device mode: needs a GPU
     assert run("-g", 2, "-D", "none", "-c", 0)[0].returncode == 2
     assert run("-D", "none")[0].returncode == 2
+
+
+def test_feeder_threads_are_pinned_and_the_line_carries_a_roofline(tmp_path):
+    """every feeder thread of the node mode pins itself to its GPU's NUMA node (dry run: node = rank modulo the nodes present, so
+    the sysfs parsing and pthread_setaffinity_np run here too) and the line says to which CPUs; it carries a roofline object whose algorithmic bytes
+    come from the preset's own delays and enables (read back through the vendor requests) and agree with bench.py's figure for the same preset."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    ref = Oracle(1); assert ref.load_bulk(WL.full_chain_blob(1)) == 0
+    (tmp_path / "bulk.bin").write_bytes(ref.collect_bulk())
+    n, blocks, B, fs = 3, 50, 96, 96000
+    r, d = run("-g", n, "-D", "none", "-f", "f32fma", "-s", 500, "-r", fs, "-b", B, "-n", blocks, "-c", 2, "-B", tmp_path / "bulk.bin")
+    assert r.returncode == 0, r.stderr
+    aff = d["affinity"]
+    assert [a["device"] for a in aff] == list(range(n))
+    nodes = 0
+    while os.path.exists(f"/sys/devices/system/node/node{nodes}/cpulist"): nodes += 1
+    if nodes:      # (containers without /sys/devices/system/node: nothing to pin to, the line says "none")
+        allowed = os.sched_getaffinity(0)
+        for a in aff:
+            assert a["numa_node"] == a["device"] % nodes and a["source"].startswith("dry")
+            cpus = set()
+            for part in open(f"/sys/devices/system/node/node{a['numa_node']}/cpulist").read().strip().split(","):
+                lo, _, hi = part.partition("-"); cpus |= set(range(int(lo), int(hi or lo) + 1))
+            assert a["cpus"] == len(cpus & allowed) > 0
+    else:
+        assert all(a["numa_node"] == -1 and a["cpus"] == 0 for a in aff)
+    alg = bench.algorithmic_bytes(bench.chain_workload("3"), blocks * B)
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 * n and roof["unit"] == "GB/s"
+    assert abs(roof["algorithmic_bytes_per_frame"] - alg["exact"]) < 1e-3 and abs(roof["algorithmic_bytes_per_frame_hbm_resident"] - alg["resident"]) < 1e-3
+    assert len(d["config"]["ms_per_step_per_device"]) == n and d["checked_streams"] == []      # (no device: nothing processed, nothing to check)

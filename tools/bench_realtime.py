@@ -41,13 +41,21 @@ def run(flavor_name, flavor, S, fs, B, calls, packets, check=True, env=None, pre
         cmd = [HOST, "-rt", "-f", flavor_name, "-s", str(S), "-r", str(fs), "-b", str(B), "-c", str(calls), "-B", os.path.join(td, "bulk.bin"),
                "-i", os.path.join(td, "pcm.raw"), "-O", os.path.join(td, "all.raw"), "-L", os.path.join(td, "lat.f64"), "-v", "-20"]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(os.environ, **(env or {})))
-        if r.returncode != 0: raise SystemExit(f"dspi_host failed: {r.stdout}\n{r.stderr}")
+        if r.returncode != 0: raise subprocess.SubprocessError(f"dspi_host failed: {r.stdout}\n{r.stderr}")      # (not a parity verdict: bench.py keeps its line)
         line = [l for l in r.stdout.splitlines() if l.startswith("rt:")][0]
         m = re.search(r"p50 ([\d.]+) us\s+p99 ([\d.]+) us\s+p99.9 ([\d.]+) us\s+max ([\d.]+) us\s+\(first (\d+) calls: max ([\d.]+) us\)\s+mean ([\d.]+) us = ([\d.]+) x real time", line)
         rec = dict(flavor=flavor_name, streams=S, fs=fs, block_len=B, calls=calls, p50_us=float(m.group(1)), p99_us=float(m.group(2)), p999_us=float(m.group(3)), max_us=float(m.group(4)),
                    preset=preset, first_calls=int(m.group(5)), first_calls_max_us=float(m.group(6)), mean_us=float(m.group(7)), realtime_x=float(m.group(8)), packet_us=B / fs * 1e6)
         lat = np.fromfile(os.path.join(td, "lat.f64"), dtype=np.float64)
         rec["over_packet_time"] = int((lat[rec["first_calls"]:] > B / fs).sum())      # calls (steady state) that took longer than the packet they carry
+        # the tail as the host prints it (dspi_host.c "rt-json:"): p99.9 / p99.99, calls over the packet time, a log2 histogram, and the library's
+        # own record of the polling path (dspi_debug_direct_stats: how many calls reached the blocking wait, the longest enqueue / wait phase)
+        js = [l for l in r.stdout.splitlines() if l.startswith("rt-json:")]
+        if js:
+            j = json.loads(js[0][len("rt-json:"):])
+            rec.update(p99_9_us=j["p99_9_us"], p99_99_us=j["p99_99_us"], n_over_packet=j["n_over_packet"], hist_log2_us=j["hist_log2_us"], direct_path=j["direct_path"])
+            worst = np.argsort(lat[rec["first_calls"]:])[-3:][::-1] + rec["first_calls"]
+            rec["worst_calls"] = [{"call": int(c), "us": float(lat[c] * 1e6)} for c in worst]
         if check:
             P, C = (4, 11) if fl else (2, 7)
             per = P * B * 2 + B          # int32 words per call and stream, then C uint16
