@@ -257,18 +257,17 @@ DSPI_DM_SLOW float dspi_det_powf_slow(float a, float b) {
     return dspi_dd_to_float(dspi_dd_exp(yy));
 }
 
-/* log10f replacement: the correctly rounded binary32 log10(x).  Domain: x > 0 (the leveller passes rms_sq + 1e-30f). */
-DSPI_DM_FN float dspi_det_log10f(float x) {
+/* Step 1 alone: the candidate, and *amb |= 1 when it is not proven (the caller then owes the value to step 2).  The device kernels use these
+ * for the leveller's three calls and take ONE out-of-line exact evaluation of the whole gain decision when any of them is unproven
+ * (dspi_kernels.hip leveller_block_gain): a call per libm function cost the per-lane-value kernels 20 % (spills around six call sites). */
+DSPI_DM_FN float dspi_det_log10f_try(float x, int *amb) {
     if (!(x > 0.0f)) return -300.0f;            /* out of contract; keep total */
     if (x == 1.0f) return 0.0f;
     float f;
-    if (dspi_dm_unambiguous(dspi_dm_log((double)x) * 0.43429448190325182, 1.4210854715202004e-14 /* 2^-46 */, &f)) return f;
-    return dspi_det_log10f_slow(x);
+    if (!dspi_dm_unambiguous(dspi_dm_log((double)x) * 0.43429448190325182, 1.4210854715202004e-14 /* 2^-46 */, &f)) *amb |= 1;
+    return f;
 }
-
-/* powf replacement: the correctly rounded binary32 a^b.  Domain: a > 0 (alpha in (0,1) ^ block_len, and 10 ^ (dB/20)); results clamp at
- * e^88 (finite) and flush to 0 below e^-103, as before. */
-DSPI_DM_FN float dspi_det_powf(float a, float b) {
+DSPI_DM_FN float dspi_det_powf_try(float a, float b, int *amb) {
     if (b == 0.0f) return 1.0f;
     if (!(a > 0.0f)) return 0.0f;               /* 0^b for b>0; negative bases out of contract */
     if (a == 1.0f) return 1.0f;
@@ -277,8 +276,23 @@ DSPI_DM_FN float dspi_det_powf(float a, float b) {
     if (y < -103.0) return 0.0f;
     float f;
     const double ay = y < 0.0 ? -y : y;
-    if (dspi_dm_unambiguous(dspi_dm_exp(y), 1.4210854715202004e-14 + ay * 7.105427357601002e-15 /* 2^-46 + |y| 2^-47 */, &f)) return f;
-    return dspi_det_powf_slow(a, b);
+    if (!dspi_dm_unambiguous(dspi_dm_exp(y), 1.4210854715202004e-14 + ay * 7.105427357601002e-15 /* 2^-46 + |y| 2^-47 */, &f)) *amb |= 1;
+    return f;
+}
+
+/* log10f replacement: the correctly rounded binary32 log10(x).  Domain: x > 0 (the leveller passes rms_sq + 1e-30f). */
+DSPI_DM_FN float dspi_det_log10f(float x) {
+    int amb = 0;
+    const float f = dspi_det_log10f_try(x, &amb);
+    return amb ? dspi_det_log10f_slow(x) : f;
+}
+
+/* powf replacement: the correctly rounded binary32 a^b.  Domain: a > 0 (alpha in (0,1) ^ block_len, and 10 ^ (dB/20)); results clamp at
+ * e^88 (finite) and flush to 0 below e^-103, as before. */
+DSPI_DM_FN float dspi_det_powf(float a, float b) {
+    int amb = 0;
+    const float f = dspi_det_powf_try(a, b, &amb);
+    return amb ? dspi_det_powf_slow(a, b) : f;
 }
 
 #endif /* DSPI_DETMATH_H */

@@ -141,6 +141,44 @@ def test_latency_layout(flavor, fs, B, depth, monkeypatch):
 
 
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
+@pytest.mark.parametrize("fs,B", [(48000, 48), (44100, 45), (96000, 192), (48000, 7)])
+def test_latency_layout_lines_of_disabled_outputs(flavor, fs, B, monkeypatch):
+    """The reference runs an output's delay line whenever its delay is non-zero, enabled or not (usb_audio.c:898-911); the latency layout's first
+    shape fetches and zeroes such lines once per batch (dspi_chain_skew.inc, "lines of disabled outputs").  What the lines HOLD must stay the
+    reference's: outputs are disabled and enabled again between calls (the line's old samples come out delayed; the zeros written while the
+    output was off come out after them), with delays shorter than a packet, of several packets, within a batch of the line's length, and at
+    the aliasing maximum; three disabled delayed outputs in one pair's reach (two take the batch path, the third the packet path), the sub
+    with its alignment delay alone, and BASELINE config 2's own preset (only the sub's line runs)."""
+    import struct
+    monkeypatch.setenv("DSPI_F32_LAYOUT", "skew")
+    blob = _latency_blob(delays=(0.4, 3.1, 84.9 if fs == 48000 else 42.0, 85.4, 0.0, 0.05, 20.0, 1.7, 10.0))
+    S, per = 21, (10 if B >= 44 else 60)
+    d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-7 * 256); assert d.load_bulk(blob) == 0
+    ors = []
+    for s in range(S):
+        o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-7 * 256); assert o.load_bulk(blob) == 0
+        ors.append(o)
+    # call by call: which outputs are enabled (output 5 starts disabled in the blob)
+    plans = [{}, {1: 0, 2: 0, 8: 0}, {3: 0, 6: 0}, {1: 1, 8: 1}, {2: 1, 3: 1, 5: 1}, {6: 1, 0: 0, 7: 0}, {0: 1, 7: 1}]
+    pcm = WL.synth_pcm16(S, B * per * len(plans), fs)
+    for c, plan in enumerate(plans):
+        for o_, en in plan.items():
+            d.vendor_set(W.REQ["SET_OUTPUT_ENABLE"], o_, struct.pack("<B", en))
+            for o in ors: o.vendor_set(W.REQ["SET_OUTPUT_ENABLE"], o_, struct.pack("<B", en))
+        x = np.ascontiguousarray(pcm[:, c * per * B:(c + 1) * per * B])
+        gp, gs, gk = d.process_host(x, per, B)
+        assert d.launch_plan()["latency_layout"] > 0 and d.launch_plan()["packed_shared"] == 0
+        for s in range(S):
+            rp, rs, rk, _ = ors[s].process(x[s], per, B)
+            assert np.array_equal(rp, gp[s]), f"call {c}, stream {s}: pairs differ at {np.argwhere(rp != gp[s])[:3].tolist()}"
+            assert np.array_equal(rs, gs[s]) and np.array_equal(rk, gk[s]), (c, s)
+            assert ors[s].status() == d.status(s), (c, s)
+    d.close()
+    # BASELINE config 2's own preset: two outputs enabled, no user delay — the sub's alignment line is the only one that runs
+    compare(flavor, fs, B, 2 * per, 19, WL.config2_blob(False), vol=-10 * 256)
+
+
+@pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
 @pytest.mark.parametrize("fs,B,depth", [(48000, 48, 16), (96000, 96, 24), (44100, 45, 16), (44100, 44, 24), (48000, 1, 16), (48000, 7, 16), (48000, 13, 16), (48000, 14, 16), (48000, 97, 16), (96000, 192, 16)])
 def test_latency_layout_output_rows(flavor, fs, B, depth, monkeypatch):
     """The latency layout's second shape (dspi_chain_skew.inc, EQO): presets whose OUTPUTS run EQs — the full chain of BASELINE config 3
