@@ -634,7 +634,7 @@ def bench_chain(args, torch, dev, rank, world, dist, backend, Dspi, W, stream_ra
     from dspi_amd.host import source_fingerprint
     SRC_SHA16 = source_fingerprint()
     alg = algorithmic_bytes(w, frames)
-    kernel_key = {"3": "chain3", "2": "chain2", "2b": "chain2", "5": "chain5", "perstream": "perstream", "perstream_eq": "perstream_eq"}[args.config]
+    kernel_key = {"3": "chain3", "2": "chain2", "2b": "chain2b", "5": "chain5", "perstream": "perstream", "perstream_eq": "perstream_eq"}[args.config]      # (2b: no counter profile of its own — its traffic fields stay null rather than borrow config 2's)
 
     def roof(m):
         per_launch_frames = S * frames

@@ -22,6 +22,7 @@
 #include <xmmintrin.h>
 #include <algorithm>
 #include <chrono>
+#include "../../include/dspi_detmath.h"
 
 #include "../../include/dspi.h"
 #include "dspi_image.h"
@@ -56,6 +57,9 @@ struct dspi_ctx {
     bool populated = false;      // DSPI_BOOT_POPULATED_FLASH: the streams are devices whose flash already holds a preset directory
     bool audio_started = false;  // a dspi_process has run: the devices are no longer booting (dspi_load_flash_dump)
     bool no_direct = false;      // DSPI_NO_DIRECT (development / tests, read once at dspi_create): the staged path for small host calls too
+    // the leveller's alpha^count on the device is step 1 + a table that was generated for the firmware's 18 alphas (include/dspi_detmath.h); the
+    // alphas this context has actually built into images, and the block length they were last checked with against the exact form
+    std::vector<uint32_t> lv_alphas; uint32_t lv_checked_count = 0; size_t lv_checked_n = 0;
     uint32_t direct_spin_us = 0; // DSPI_DIRECT_SPIN_US (read once at dspi_create): how long a direct call polls its stream before the blocking wait; 0 = the call's own audio time (>= 300 us)
     uint64_t direct_stats[5] = {0, 0, 0, 0, 0};      // dspi_debug_direct_stats: calls, calls that fell back to the blocking wait, max enqueue ns, max wait ns, last spin budget ns
     // device
@@ -605,6 +609,10 @@ int commit_params(dspi_ctx *c) {
             const size_t ii = i + k;
             if ((c->image_flags[ii] ^ run[k].flags) & IF_LEVELLER_ON) c->launch_dirty = true;
             c->image_flags[ii] = run[k].flags;
+            for (const float al : {run[k].lv_alpha_attack, run[k].lv_alpha_release}) {
+                uint32_t bits; memcpy(&bits, &al, 4);
+                if (std::find(c->lv_alphas.begin(), c->lv_alphas.end(), bits) == c->lv_alphas.end()) c->lv_alphas.push_back(bits);
+            }
             if (c->flavor) {
                 if (memcmp(&run_sig[k], &c->image_sig[ii], sizeof(dspi_ctx::ImageSig)) != 0) { c->image_sig[ii] = run_sig[k]; c->launch_dirty = true; }
                 if (run_bands[k].a != c->image_bands[ii].a || run_bands[k].b != c->image_bands[ii].b) { c->image_bands[ii] = run_bands[k]; c->launch_dirty = true; }
@@ -915,7 +923,7 @@ int dspi_debug_eq_taps(dspi_ctx *c, int32_t stream, int channel, const float *x,
 }
 
 int dspi_debug_detmath(dspi_ctx *c, int which, const float *a, const float *b, uint32_t n, float *out) {
-    if (!c || !a || !out || (which && !b) || n == 0 || n > (1u << 24) || (which != 0 && which != 1)) return DSPI_E_INVAL;
+    if (!c || !a || !out || ((which == 1 || which == 4) && !b) || n == 0 || n > (1u << 24) || which < 0 || which > 4) return DSPI_E_INVAL;
     if (c->device == DSPI_DEVICE_NONE) return fail(c, DSPI_E_NODEVICE, "host-only context: the HIP path is the only audio path");
     HIPCK(c, hipSetDevice(c->device));
     float *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
@@ -923,7 +931,7 @@ int dspi_debug_detmath(dspi_ctx *c, int which, const float *a, const float *b, u
     auto done = [&](int rc) { (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o); return rc; };
     if (hipMalloc((void **)&d_a, nb) != hipSuccess || hipMalloc((void **)&d_b, nb) != hipSuccess || hipMalloc((void **)&d_o, nb) != hipSuccess)
         return done(fail(c, DSPI_E_NOMEM, "hipMalloc failed (detmath)"));
-    if (hipMemcpy(d_a, a, nb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_b, which ? b : a, nb, hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(d_a, a, nb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_b, (which == 1 || which == 4) ? b : a, nb, hipMemcpyHostToDevice) != hipSuccess ||
         launch_detmath(which, d_a, d_b, n, d_o, c->hs) != hipSuccess || hipStreamSynchronize(c->hs) != hipSuccess ||
         hipMemcpy(out, d_o, nb, hipMemcpyDeviceToHost) != hipSuccess)
         return done(fail(c, DSPI_E_HIP, "detmath kernel failed"));
@@ -1063,6 +1071,16 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     HIPCK(c, hipSetDevice(c->device));
     int rc = commit_params(c);
     if (rc) return rc;
+    // alpha^count (leveller.c:200) on the device = step 1 of include/dspi_detmath.h's powf + its exception table; proven equal to the exact form
+    // for the firmware's alphas and every block length by tools/gen_detmath_tables.c — and checked here for the pairs this context really uses
+    if (c->lv_checked_count != block_len || c->lv_checked_n != c->lv_alphas.size()) {
+        for (const uint32_t bits : c->lv_alphas) {
+            float al; memcpy(&al, &bits, 4);
+            const float t = dspi_det_powf_tab(al, (float)block_len), e = dspi_det_powf(al, (float)block_len);
+            if (memcmp(&t, &e, 4) != 0) return fail(c, DSPI_E_UNSUPPORTED, "leveller alpha^count: this (alpha, block length) is not covered by the device's exception table (include/dspi_detmath_tables.h)");
+        }
+        c->lv_checked_count = block_len; c->lv_checked_n = c->lv_alphas.size();
+    }
 
     const size_t frames = (size_t)n_blocks * block_len;
     const size_t in_b = (size_t)c->n_streams * frames * (bit_depth == 24 ? 6 : 4);
@@ -1233,8 +1251,9 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
             const auto t_end = std::chrono::steady_clock::now();
             const uint64_t enq = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(spin_t0 - call_t0).count();
             const uint64_t wait = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_end - spin_t0).count();
-            c->direct_stats[0]++; c->direct_stats[1] += fell_back ? 1u : 0u;
+            c->direct_stats[0]++;
             if (c->direct_stats[0] > 8) {      // (the context's first calls allocate the pinned area, build the launch lists, load the code objects: not the steady state)
+                c->direct_stats[1] += fell_back ? 1u : 0u;
                 c->direct_stats[2] = std::max(c->direct_stats[2], enq); c->direct_stats[3] = std::max(c->direct_stats[3], wait);
             }
             c->direct_stats[4] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(budget).count();

@@ -216,31 +216,12 @@ __device__ __forceinline__ float gain_computer(float x_db, float thr, float rati
     return (thr - x_db) * (1.0f - 1.0f / ratio);
 }
 
-// per-packet gain decision, leveller.c:174-206 (float) == :304-332 (Q28); libm -> dspi_detmath.h
-struct LvNums { float alpha_attack, alpha_release, threshold_db, ratio, knee_db, makeup_db, gate_db, max_gain_db; };
-// ... with the exact (two-step) functions, out of line: taken when one of the three first-step values below is not proven (~3 decisions in 10^6)
-template <bool FMA>
-__device__ __attribute__((noinline)) float leveller_block_gain_exact(LvNums p, float *gsm_io, float rms_sq, uint32_t count) {
-    const float rms_db = 10.0f * dspi_det_log10f(rms_sq + 1e-30f);
-    float gc;
-    if (rms_db < p.gate_db) gc = 0.0f;
-    else {
-        gc = gain_computer(rms_db, p.threshold_db, p.ratio, p.knee_db);
-        gc += p.makeup_db;
-        if (gc > p.max_gain_db) gc = p.max_gain_db;
-    }
-    const float gsm_db = *gsm_io;
-    const float a_s = (gc < gsm_db) ? p.alpha_attack : p.alpha_release;
-    const float alpha = dspi_det_powf(a_s, (float)count);
-    const float g2 = mad1<FMA>(alpha, gsm_db, (1.0f - alpha) * gc);      // leveller.c:200
-    *gsm_io = g2;
-    return dspi_det_powf(10.0f, g2 / 20.0f);
-}
+// per-packet gain decision, leveller.c:174-206 (float) == :304-332 (Q28); libm -> dspi_detmath.h: the correctly rounded log10f, a^count and
+// 10^y in their DEVICE forms (step 1 + the exception tables of include/dspi_detmath_tables.h — the same floats as the oracle's two-step
+// functions for every argument, without the double-double code, whose mere presence cost the headline kernel 2 %: profiles/r06_detmath.md)
 template <bool FMA = false, class IMG>
 __device__ __forceinline__ float leveller_block_gain(IMG img, float &gsm_db, float rms_sq, uint32_t count) {
-    // first steps only (include/dspi_detmath.h: the value and whether it is proven); one exact evaluation of the whole decision otherwise
-    int amb = 0;
-    float rms_db = 10.0f * dspi_det_log10f_try(rms_sq + 1e-30f, &amb);
+    float rms_db = 10.0f * dspi_det_log10f_tab(rms_sq + 1e-30f);
     float gc;
     if (rms_db < img->lv_gate_db) gc = 0.0f;
     else {
@@ -249,18 +230,9 @@ __device__ __forceinline__ float leveller_block_gain(IMG img, float &gsm_db, flo
         if (gc > img->lv_max_gain_db) gc = img->lv_max_gain_db;
     }
     float a_s = (gc < gsm_db) ? img->lv_alpha_attack : img->lv_alpha_release;
-    float alpha = dspi_det_powf_try(a_s, (float)count, &amb);
-    const float g2 = mad1<FMA>(alpha, gsm_db, (1.0f - alpha) * gc);      // leveller.c:200
-    const float out = dspi_det_powf_try(10.0f, g2 / 20.0f, &amb);
-    if (__builtin_expect(amb != 0, 0)) {
-        const LvNums p{img->lv_alpha_attack, img->lv_alpha_release, img->lv_threshold_db, img->lv_ratio, img->lv_knee_db, img->lv_makeup_db, img->lv_gate_db, img->lv_max_gain_db};
-        float g = gsm_db;
-        const float r = leveller_block_gain_exact<FMA>(p, &g, rms_sq, count);
-        gsm_db = g;
-        return r;
-    }
-    gsm_db = g2;
-    return out;
+    float alpha = dspi_det_powf_tab(a_s, (float)count);          // (the host has checked this context's alphas and block length against the exact form)
+    gsm_db = mad1<FMA>(alpha, gsm_db, (1.0f - alpha) * gc);      // leveller.c:200
+    return dspi_det_exp10f_tab(gsm_db / 20.0f);                   // leveller.c:206: powf(10.0f, x)
 }
 
 // Workgroup barrier for the chunk hand-off.  The only data exchanged between waves inside the time loop

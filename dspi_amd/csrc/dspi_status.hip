@@ -19,7 +19,15 @@ namespace {
 __global__ __launch_bounds__(256) void detmath_kernel(int which, const float *a, const float *b, uint32_t n, float *out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    out[i] = which ? dspi_det_powf(a[i], b[i]) : dspi_det_log10f(a[i]);
+    float r;
+    switch (which) {      // 0 / 1: the two-step forms (the oracle's); 2 / 3 / 4: the device forms the chain kernels use
+        case 0: r = dspi_det_log10f(a[i]); break;
+        case 1: r = dspi_det_powf(a[i], b[i]); break;
+        case 2: r = dspi_det_log10f_tab(a[i]); break;
+        case 3: r = dspi_det_exp10f_tab(a[i]); break;
+        default: r = dspi_det_powf_tab(a[i], b[i]); break;
+    }
+    out[i] = r;
 }
 
 __global__ __launch_bounds__(256) void clip_gather_kernel(const uint32_t *state, uint32_t n_streams, uint32_t row, uint32_t n_slots, uint32_t clip_slot, uint16_t *out) {

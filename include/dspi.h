@@ -285,13 +285,14 @@ int dspi_debug_image(dspi_ctx *ctx, int32_t stream, void *buf, size_t cap);
  * presets of one structure at once (a workgroup's stream slots each read their own image).  Returns the number of counts written
  * (5, 6 or 7) or a negative DSPI_E_*. */
 int dspi_debug_launch_plan(dspi_ctx *ctx, uint32_t *counts, size_t n_counts);
-/* include/dspi_detmath.h's log10f (which = 0: out[i] = log10f(a[i]), b unused) / powf (which = 1: out[i] = powf(a[i], b[i])) evaluated on the DEVICE,
- * host buffers, n <= 2^24: tests compare them bit for bit with the host build of the same header and with binary128. */
+/* include/dspi_detmath.h evaluated on the DEVICE, host buffers, n <= 2^24: which = 0: out[i] = log10f(a[i]) and 1: powf(a[i], b[i]) in the two-step
+ * forms; 2: log10f, 3: 10^a[i], 4: a[i]^b[i] in the forms the chain kernels use (step 1 + exception tables).  Tests compare all of them bit for
+ * bit with the host build of the same header and with binary128. */
 int dspi_debug_detmath(dspi_ctx *ctx, int which, const float *a, const float *b, uint32_t n, float *out);
 /* Small calls on host buffers (one packet per call, usb_audio.c:1326-1332) poll the context's stream instead of sleeping on it: for the audio
  * time the call carries (frames at 44.1 kHz; at least 300 us, at most 50 ms; DSPI_DIRECT_SPIN_US, read at dspi_create, overrides), then the
  * blocking wait.  out[5] = {such calls so far, calls that reached the blocking wait, longest enqueue phase in ns (entry -> launches issued),
- * longest wait phase in ns (both over the calls after the context's first eight), the last call's polling budget in ns}.  tools/bench_realtime.py reports them next to the latency percentiles.
+ * longest wait phase in ns (these three over the calls after the context's first eight), the last call's polling budget in ns}.  tools/bench_realtime.py reports them next to the latency percentiles.
  * Returns 5 or a negative DSPI_E_*. */
 int dspi_debug_direct_stats(dspi_ctx *ctx, uint64_t *out, size_t n);
 /* Number of distinct parameter objects the context holds (streams share one until a per-stream call separates them; streams that

@@ -230,17 +230,30 @@ DSPI_DM_FN float dspi_dd_to_float(dspi_dd v) {
     return (float)mid;                           /* the midpoint itself: ties to even (the conversion's own rule) */
 }
 
-/* do r (1 - eps) and r (1 + eps) round to the same float? */
-DSPI_DM_FN int dspi_dm_unambiguous(double r, double eps, float *out) {
+/* Do all of [r (1 - eps), r (1 + eps)] round to the same float, i.e. does the interval hold no midpoint of two adjacent floats?
+ * Where the float is normal: a midpoint is a double whose low 29 significand bits are 1 0000...0, and eps |r| is at most eps 2^53 ulps of r,
+ * so three integer operations on the low word decide (the interval cannot reach a midpoint of a neighbouring binade: the nearest lies 2^27
+ * ulps beyond the binade's edge).  `ulps` = ceil(eps 2^53) + 2, at most 2^27.  Otherwise (float subnormal, zero, overflow) by conversion. */
+DSPI_DM_FN int dspi_dm_unambiguous_u(double r, double eps, uint32_t ulps, float *out) {
+    const uint64_t u = dspi_dm_bits(r);
+    const uint32_t e = (uint32_t)(u >> 52) & 0x7ffu;
+    if (e >= 1023u - 126u && e <= 1023u + 126u) {
+        *out = (float)r;
+        return (((uint32_t)u & 0x1fffffffu) - (0x10000000u - ulps)) > 2u * ulps;
+    }
     const double d = (r < 0.0 ? -r : r) * eps;
     const float lo = (float)(r - d), hi = (float)(r + d);
     *out = lo;
     return lo == hi;
 }
+DSPI_DM_FN int dspi_dm_unambiguous(double r, double eps, float *out) {
+    double w = eps * 9007199254740992.0;        /* 2^53 */
+    if (w > 134217000.0) w = 134217000.0;
+    return dspi_dm_unambiguous_u(r, eps, (uint32_t)w + 3u, out);
+}
 
-/* Step 2 as functions of their own.  On the device they are NOT inlined: step 2 runs for ~1 call in 10^6, and inlined into a kernel that
- * already uses every register of its occupancy class it costs the common path spills (measured: 48-112 B/lane of scratch in the packed
- * leveller kernels); as a call it costs the rare path a stack frame. */
+/* Step 2 as functions of their own (on the device not inlined: only the test kernel dspi_debug_detmath evaluates them there; the chain kernels
+ * use the table forms at the end of this header). */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DSPI_DM_SLOW static __device__ __attribute__((noinline))
 #elif defined(__HIPCC__)
@@ -257,14 +270,12 @@ DSPI_DM_SLOW float dspi_det_powf_slow(float a, float b) {
     return dspi_dd_to_float(dspi_dd_exp(yy));
 }
 
-/* Step 1 alone: the candidate, and *amb |= 1 when it is not proven (the caller then owes the value to step 2).  The device kernels use these
- * for the leveller's three calls and take ONE out-of-line exact evaluation of the whole gain decision when any of them is unproven
- * (dspi_kernels.hip leveller_block_gain): a call per libm function cost the per-lane-value kernels 20 % (spills around six call sites). */
+/* Step 1 alone: the candidate, and *amb |= 1 when it is not proven (the caller then owes the value to step 2, or to the exception tables). */
 DSPI_DM_FN float dspi_det_log10f_try(float x, int *amb) {
     if (!(x > 0.0f)) return -300.0f;            /* out of contract; keep total */
     if (x == 1.0f) return 0.0f;
     float f;
-    if (!dspi_dm_unambiguous(dspi_dm_log((double)x) * 0.43429448190325182, 1.4210854715202004e-14 /* 2^-46 */, &f)) *amb |= 1;
+    if (!dspi_dm_unambiguous_u(dspi_dm_log((double)x) * 0.43429448190325182, 1.4210854715202004e-14 /* 2^-46 */, 130u /* 2^7 + 2 */, &f)) *amb |= 1;
     return f;
 }
 DSPI_DM_FN float dspi_det_powf_try(float a, float b, int *amb) {
@@ -294,5 +305,76 @@ DSPI_DM_FN float dspi_det_powf(float a, float b) {
     const float f = dspi_det_powf_try(a, b, &amb);
     return amb ? dspi_det_powf_slow(a, b) : f;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The DEVICE's forms (round 6): step 1 + a table of exceptions instead of step 2.
+ *
+ * Why: step 2 in a kernel that uses every register of its occupancy class is not free even when it never runs — its scalar and vector
+ * registers leak into the hot loops' allocation (measured on the headline kernel: +2.0 .. +2.6 % with step 2 inlined or called, 0 % with
+ * step 1 alone; profiles/r06_detmath.md).  log10f has 2^31 arguments and 10^y 2^32: tools/gen_detmath_tables.c walks ALL of them, takes
+ * those whose step-1 value is not proven (~10^3), evaluates them exactly, and keeps the few whose step-1 candidate is the wrong neighbour.
+ * So for EVERY binary32 argument: proven -> the candidate; not proven -> the table's value if the argument is listed, else the candidate —
+ * the correctly rounded result either way, the same float the two-step functions above return (tests/test_detmath.py re-walks both ranges).
+ * a^b in general has no such table; the leveller's a^count has 18 bases (three speeds x attack / release x three rates, leveller.c:37-89)
+ * and counts 1 .. 192: the generator walks those, +-8 ulps around every base; a context whose actual (alpha, count) falls outside is
+ * refused by the host, which compares the two forms when it builds the parameter image (dspi_params.cpp).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t in, out; } dspi_dm_exc;
+typedef struct { uint32_t a, b, out; } dspi_dm_exc2;
+#ifndef DSPI_DM_NO_TABLES
+#include "dspi_detmath_tables.h"
+#endif
+/* what dspi_dm_log(10.0) returns, to the bit (tests/test_detmath.py): 10^y below is then the same binary64 value as step 1 of powf(10, y) */
+#define DSPI_DM_LOG_OF_10 2.3025850929940455
+
+DSPI_DM_FN uint32_t dspi_dm_fbits(float f) {
+#ifdef __cplusplus
+    return DSPI_DM_BITCAST(uint32_t, f);
+#else
+    union { float f; uint32_t u; } c; c.f = f; return c.u;
+#endif
+}
+DSPI_DM_FN float dspi_dm_ffrom(uint32_t u) {
+#ifdef __cplusplus
+    return DSPI_DM_BITCAST(float, u);
+#else
+    union { float f; uint32_t u; } c; c.u = u; return c.f;
+#endif
+}
+/* step 1 of 10^y alone (the value powf(10, y)'s step 1 computes, without re-deriving log 10) */
+DSPI_DM_FN float dspi_det_exp10f_try(float y, int *amb) {
+    if (y == 0.0f) return 1.0f;
+    double yd = (double)y * DSPI_DM_LOG_OF_10;
+    if (yd > 88.0) yd = 88.0;
+    if (yd < -103.0) return 0.0f;
+    float f;
+    const double ay = yd < 0.0 ? -yd : yd;
+    if (!dspi_dm_unambiguous(dspi_dm_exp(yd), 1.4210854715202004e-14 + ay * 7.105427357601002e-15, &f)) *amb |= 1;
+    return f;
+}
+#ifndef DSPI_DM_NO_TABLES
+DSPI_DM_FN float dspi_det_log10f_tab(float x) {
+    static const dspi_dm_exc t[DSPI_DM_LOG10_EXC_N + 1] = DSPI_DM_LOG10_EXC;
+    int amb = 0;
+    float f = dspi_det_log10f_try(x, &amb);
+    if (amb) { const uint32_t k = dspi_dm_fbits(x); for (int i = 0; i < DSPI_DM_LOG10_EXC_N; ++i) if (t[i].in == k) f = dspi_dm_ffrom(t[i].out); }
+    return f;
+}
+DSPI_DM_FN float dspi_det_exp10f_tab(float y) {
+    static const dspi_dm_exc t[DSPI_DM_EXP10_EXC_N + 1] = DSPI_DM_EXP10_EXC;
+    int amb = 0;
+    float f = dspi_det_exp10f_try(y, &amb);
+    if (amb) { const uint32_t k = dspi_dm_fbits(y); for (int i = 0; i < DSPI_DM_EXP10_EXC_N; ++i) if (t[i].in == k) f = dspi_dm_ffrom(t[i].out); }
+    return f;
+}
+/* the leveller's alpha^count (see above): correct on the walked (base, count) set; the host checks the actual pair against dspi_det_powf */
+DSPI_DM_FN float dspi_det_powf_tab(float a, float b) {
+    static const dspi_dm_exc2 t[DSPI_DM_POW_EXC_N + 1] = DSPI_DM_POW_EXC;
+    int amb = 0;
+    float f = dspi_det_powf_try(a, b, &amb);
+    if (amb) { const uint32_t ka = dspi_dm_fbits(a), kb = dspi_dm_fbits(b); for (int i = 0; i < DSPI_DM_POW_EXC_N; ++i) if (t[i].a == ka && t[i].b == kb) f = dspi_dm_ffrom(t[i].out); }
+    return f;
+}
+#endif
 
 #endif /* DSPI_DETMATH_H */

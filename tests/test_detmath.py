@@ -182,6 +182,59 @@ def test_distance_to_glibc_is_reported(lib):
     assert worst <= 2
 
 
+def test_device_forms_equal_the_exact_ones(lib):
+    """The forms the chain kernels use (step 1 + exception tables, include/dspi_detmath.h) against the two-step forms: every listed exception,
+    the arguments around them, the sweeps' ranges; 10^y against powf(10, y), its clamp and flush edges included."""
+    src = os.path.join(ROOT, "tests", "_detmath_tab.c")
+    open(src, "w").write('#include "../include/dspi_detmath.h"\n'
+                         'void tab_log10(const float*x,float*y,long n){for(long i=0;i<n;i++)y[i]=dspi_det_log10f_tab(x[i]);}\n'
+                         'void tab_exp10(const float*x,float*y,long n){for(long i=0;i<n;i++)y[i]=dspi_det_exp10f_tab(x[i]);}\n'
+                         'void tab_pow(const float*a,const float*b,float*y,long n){for(long i=0;i<n;i++)y[i]=dspi_det_powf_tab(a[i],b[i]);}\n'
+                         'double log_of_10(void){return dspi_dm_log(10.0);} double log_of_10_const(void){return DSPI_DM_LOG_OF_10;}\n')
+    so = os.path.join(ROOT, "tests", "_detmath_tab.so")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src], check=True)
+    T = ctypes.CDLL(so)
+    vp, lg = ctypes.c_void_p, ctypes.c_long
+    T.tab_log10.argtypes = [vp, vp, lg]; T.tab_exp10.argtypes = [vp, vp, lg]; T.tab_pow.argtypes = [vp, vp, vp, lg]
+    T.log_of_10.restype = ctypes.c_double; T.log_of_10_const.restype = ctypes.c_double
+    assert T.log_of_10() == T.log_of_10_const()
+    import re
+    tab = open(os.path.join(ROOT, "include", "dspi_detmath_tables.h")).read()
+    def entries(name):
+        body = re.search(r"#define %s \{(.*?)\}\s*$" % name, tab, re.M).group(1)
+        return [(int(a, 16), int(b, 16)) for a, b in re.findall(r"\{0x([0-9a-f]+)u, 0x([0-9a-f]+)u\}", body)]
+    rng = np.random.default_rng(5)
+    for name, fn, exact in (("DSPI_DM_LOG10_EXC", T.tab_log10, lambda x, y: lib.t_log10f_v(x.ctypes.data, y.ctypes.data, len(x))),
+                            ("DSPI_DM_EXP10_EXC", T.tab_exp10, lambda x, y: (lambda ten: lib.t_powf_v(ten.ctypes.data, x.ctypes.data, y.ctypes.data, len(x)))(np.full_like(x, 10.0)))):
+        ex = entries(name)
+        assert 1 <= len(ex) <= 64
+        bits = np.array([e[0] for e in ex], np.uint32)
+        around = (bits[:, None].astype(np.int64) + np.arange(-64, 65)[None, :]).astype(np.uint32).reshape(-1)
+        if name == "DSPI_DM_LOG10_EXC": extra = (10 ** rng.uniform(-38, 38, 400000)).astype(np.float32)
+        else: extra = np.concatenate([rng.uniform(-46, 39, 400000), [0.0, 38.2, 38.3, 38.5, 39.0, -44.7, -44.8, -45.0, 1e-10, -1e-10], rng.uniform(-2, 2, 200000)]).astype(np.float32)
+        x = np.concatenate([around.view(np.float32), extra])
+        x = x[np.isfinite(x)]
+        got = np.empty_like(x); ref = np.empty_like(x)
+        fn(x.ctypes.data, got.ctypes.data, len(x)); exact(x, ref)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), name
+        ours = np.empty(len(ex), np.float32); fn(bits.view(np.float32).ctypes.data, ours.ctypes.data, len(ex))
+        assert np.array_equal(ours.view(np.uint32), np.array([e[1] for e in ex], np.uint32))
+    # a^count on the firmware's alphas (leveller.c:37-89) x every block length
+    al = np.array([np.exp(np.float32(-np.log(np.float32(10.0)) / np.float32(fs * t))) for fs in (44100.0, 48000.0, 96000.0) for t in (0.1, 2.0, 0.05, 1.0, 0.02, 0.5)], np.float32)
+    a = np.repeat(al, 192); b = np.tile(np.arange(1, 193, dtype=np.float32), len(al))
+    got = np.empty_like(a); ref = np.empty_like(a)
+    T.tab_pow(a.ctypes.data, b.ctypes.data, got.ctypes.data, len(a)); lib.t_powf_v(a.ctypes.data, b.ctypes.data, ref.ctypes.data, len(a))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_tables_regenerate(tmp_path):
+    """tools/gen_detmath_tables.c walks every binary32 argument of log10f and 10^y again (~20 s on 8 cores) and must print the committed tables."""
+    exe = tmp_path / "gen"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-DDSPI_DM_NO_TABLES", "-o", str(exe), os.path.join(ROOT, "tools", "gen_detmath_tables.c"), "-lquadmath", "-lm", "-lpthread"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True, timeout=900).stdout
+    assert out == open(os.path.join(ROOT, "include", "dspi_detmath_tables.h")).read()
+
+
 def test_constants_regenerate():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_detmath_consts

@@ -43,4 +43,18 @@ def test_device_equals_host_equals_binary128():
     L.t_powf_v(a.ctypes.data, b.ctypes.data, host.ctypes.data, a.size); L.q_powf_v(a.ctypes.data, b.ctypes.data, exact.ctypes.data, a.size)
     dev = device(d, 1, a, b)
     assert np.array_equal(dev.view(np.uint32), host.view(np.uint32)) and np.array_equal(dev.view(np.uint32), exact.view(np.uint32))
+    # the forms the chain kernels use (step 1 + exception tables): the same floats, on the device, the listed exceptions included
+    import os, re
+    tab = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dspi_detmath_tables.h")).read()
+    def listed(name): return np.array([int(m, 16) for m in re.findall(r"\{0x([0-9a-f]+)u, 0x[0-9a-f]+u\}", re.search(r"#define %s \{(.*?)\}\s*$" % name, tab, re.M).group(1))], np.uint32)
+    xl = np.concatenate([x, np.repeat(listed("DSPI_DM_LOG10_EXC").view(np.float32), 70)]).astype(np.float32)
+    ref = np.empty_like(xl); L.t_log10f_v(xl.ctypes.data, ref.ctypes.data, xl.size)
+    assert np.array_equal(device(d, 2, xl).view(np.uint32), ref.view(np.uint32))
+    ye = np.concatenate([rng.uniform(-46, 39, 1_000_000), rng.uniform(-2, 2, 1_000_000), np.repeat(listed("DSPI_DM_EXP10_EXC").view(np.float32), 70), [0.0, 38.5, 39.0, -44.8, -45.0]]).astype(np.float32)
+    ten = np.full_like(ye, 10.0); ref = np.empty_like(ye); L.t_powf_v(ten.ctypes.data, ye.ctypes.data, ref.ctypes.data, ye.size)
+    assert np.array_equal(device(d, 3, ye).view(np.uint32), ref.view(np.uint32))
+    al = np.array([np.exp(np.float32(-np.log(np.float32(10.0)) / np.float32(fs * t))) for fs in (44100.0, 48000.0, 96000.0) for t in (0.1, 2.0, 0.05, 1.0, 0.02, 0.5)], np.float32)
+    pa = np.repeat(al, 192); pb = np.tile(np.arange(1, 193, dtype=np.float32), len(al))
+    ref = np.empty_like(pa); L.t_powf_v(pa.ctypes.data, pb.ctypes.data, ref.ctypes.data, pa.size)
+    assert np.array_equal(device(d, 4, pa, pb).view(np.uint32), ref.view(np.uint32))
     d.close()

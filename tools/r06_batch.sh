@@ -1,8 +1,8 @@
-mkdir -p gpurun_out/r06d
-(time python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "latency_layout or config2" 2>&1 | tail -15) > gpurun_out/r06d/gputest_latency.log 2>&1
-(time python -m pytest tests -m gpu -q -x 2>&1 | tail -15) > gpurun_out/r06d/gputest.log 2>&1
-bash tools/ab_bench.sh "libsk1.so libdspi_mi355x.so" 2 --config 2 > gpurun_out/r06d/ab_config2.log 2>&1
-bash tools/ab_bench.sh "libsk1.so libdspi_mi355x.so" 2 --config 2b > gpurun_out/r06d/ab_config2b.log 2>&1
-bash tools/ab_bench.sh "libr05.so libdspi_mi355x.so" 2 --config perstream_eq --out-layout tiled > gpurun_out/r06d/ab_perstream_eq_tiled.log 2>&1
-bash tools/ab_bench.sh "libr05.so libdspi_mi355x.so" 2 --config perstream > gpurun_out/r06d/ab_perstream.log 2>&1
-tail -4 gpurun_out/r06d/gputest_latency.log; tail -4 gpurun_out/r06d/gputest.log; cat gpurun_out/r06d/ab_*.log
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r06i; mkdir -p $O
+bash tools/ab_bench.sh "libr05.so libinl.so libnostep2.so" 3 > $O/ab_default.log 2>&1
+bash tools/ab_bench.sh "libr05.so libinl.so" 2 --out-layout tiled > $O/ab_tiled.log 2>&1
+bash tools/ab_bench.sh "libr05.so libinl.so" 2 --config perstream > $O/ab_perstream.log 2>&1
+bash tools/ab_bench.sh "libr05.so libinl.so" 2 --config perstream_eq --out-layout tiled > $O/ab_perstream_eq_tiled.log 2>&1
+(cd tools/probe && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o probe12 probe12.hip && ./probe12) > $O/probe12.md 2>&1
+for f in $O/ab_*.log; do echo $f; cat $f; done; cat $O/probe12.md
