@@ -354,25 +354,22 @@ DSPI_DM_FN float dspi_det_exp10f_try(float y, int *amb) {
 }
 #ifndef DSPI_DM_NO_TABLES
 DSPI_DM_FN float dspi_det_log10f_tab(float x) {
-    static const dspi_dm_exc t[DSPI_DM_LOG10_EXC_N + 1] = DSPI_DM_LOG10_EXC;
     int amb = 0;
     float f = dspi_det_log10f_try(x, &amb);
-    if (amb) { const uint32_t k = dspi_dm_fbits(x); for (int i = 0; i < DSPI_DM_LOG10_EXC_N; ++i) if (t[i].in == k) f = dspi_dm_ffrom(t[i].out); }
+    if (amb) { const uint32_t k = dspi_dm_fbits(x); DSPI_DM_LOG10_EXC_FIX(k, f); }
     return f;
 }
 DSPI_DM_FN float dspi_det_exp10f_tab(float y) {
-    static const dspi_dm_exc t[DSPI_DM_EXP10_EXC_N + 1] = DSPI_DM_EXP10_EXC;
     int amb = 0;
     float f = dspi_det_exp10f_try(y, &amb);
-    if (amb) { const uint32_t k = dspi_dm_fbits(y); for (int i = 0; i < DSPI_DM_EXP10_EXC_N; ++i) if (t[i].in == k) f = dspi_dm_ffrom(t[i].out); }
+    if (amb) { const uint32_t k = dspi_dm_fbits(y); DSPI_DM_EXP10_EXC_FIX(k, f); }
     return f;
 }
 /* the leveller's alpha^count (see above): correct on the walked (base, count) set; the host checks the actual pair against dspi_det_powf */
 DSPI_DM_FN float dspi_det_powf_tab(float a, float b) {
-    static const dspi_dm_exc2 t[DSPI_DM_POW_EXC_N + 1] = DSPI_DM_POW_EXC;
     int amb = 0;
     float f = dspi_det_powf_try(a, b, &amb);
-    if (amb) { const uint32_t ka = dspi_dm_fbits(a), kb = dspi_dm_fbits(b); for (int i = 0; i < DSPI_DM_POW_EXC_N; ++i) if (t[i].a == ka && t[i].b == kb) f = dspi_dm_ffrom(t[i].out); }
+    if (amb) { const uint32_t ka = dspi_dm_fbits(a), kb = dspi_dm_fbits(b); DSPI_DM_POW_EXC_FIX(ka, kb, f); }
     return f;
 }
 #endif

@@ -93,5 +93,13 @@ int main(void) {
     printf(" {0u, 0u} }\n#define DSPI_DM_POW_EXC_N %d\n#define DSPI_DM_POW_EXC {", n_pw);
     for (int i = 0; i < n_pw; i++) printf(" {0x%08xu, 0x%08xu, 0x%08xu},", pw[i].a, pw[i].b, pw[i].out);
     printf(" {0u, 0u, 0u} }\n");
+    /* the same lists as compare chains (what the device forms use: immediates in a cold block, no table in memory, no loop registers) */
+    printf("#define DSPI_DM_LOG10_EXC_FIX(k, f) do {");
+    for (int i = 0; i < n_lg; i++) printf(" %sif ((k) == 0x%08xu) (f) = dspi_dm_ffrom(0x%08xu);", i ? "else " : "", lg[i].in, lg[i].out);
+    printf(" } while (0)\n#define DSPI_DM_EXP10_EXC_FIX(k, f) do {");
+    for (int i = 0; i < n_ex; i++) printf(" %sif ((k) == 0x%08xu) (f) = dspi_dm_ffrom(0x%08xu);", i ? "else " : "", ex[i].in, ex[i].out);
+    printf(" } while (0)\n#define DSPI_DM_POW_EXC_FIX(ka, kb, f) do {");
+    for (int i = 0; i < n_pw; i++) printf(" %sif ((ka) == 0x%08xu && (kb) == 0x%08xu) (f) = dspi_dm_ffrom(0x%08xu);", i ? "else " : "", pw[i].a, pw[i].b, pw[i].out);
+    printf(" (void)(ka); (void)(kb); } while (0)\n");
     return 0;
 }
