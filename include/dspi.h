@@ -26,15 +26,21 @@
  * exactly the fused multiply-adds GCC gives the firmware.  All match oracle/ bit-for-bit (tests/).
  * ONE boundary is defined by this repository rather than by the reference: the leveller calls
  * log10f once and powf twice per packet (leveller.c:178, :200, :206), the firmware links them from
- * an unpinned newlib / pico-float, and no libm agrees with another in the last bit.  Both the
- * product and the oracle therefore compute them with include/dspi_detmath.h (binary64 add / mul /
- * div only), and the reference build used for pinning is compiled with oracle/ref_math_hook.h
- * (-include), which routes leveller.c's log10f / powf to the same header — the reference build is
- * MODIFIED at exactly this boundary and nowhere else.  Measured distance (tests/test_detmath.py):
- * <= 1 ulp from the correctly rounded result (under 1 in 10^4 arguments differ at all), <= 2 ulp
- * from glibc's log10f / powf over the leveller's argument ranges; one golden vector crosses the
- * boundary: tests/golden/f32_full_96k_libm.npz (the reference with glibc's own libm, BASELINE
- * config 3's preset) is reproduced word for word by the oracle and by the GPU.
+ * an unpinned newlib / pico-float, and no libm agrees with another in the last bit.  The definition
+ * here is one anyone can reproduce: the IEEE-754 CORRECTLY ROUNDED binary32 value (round to nearest,
+ * ties to even) of log10(x) and of a^b — for every binary32 argument of log10f and of 10^y, and for
+ * a^count on the firmware's eighteen smoothing coefficients (leveller.c:37-89) with count 1..192,
+ * which are all the calls the leveller makes (results above e^88 clamp there, below e^-103 flush to 0).
+ * include/dspi_detmath.h computes it (binary64 with a proven bound, double-double where the bound does
+ * not decide; the kernels: the same floats through exception tables from an exhaustive walk,
+ * include/dspi_detmath_tables.h); tests compare it with binary128 (libquadmath): 0 mismatches over
+ * 10^7 arguments per function and over every argument the first step does not prove.  The product
+ * and the oracle both use it, and the reference build used for pinning is compiled with
+ * oracle/ref_math_hook.h (-include), which routes leveller.c's log10f / powf to the same header — the
+ * reference build is MODIFIED at exactly this boundary and nowhere else.  glibc's own log10f / powf
+ * differ from the correctly rounded value in ~2 % of calls, by at most 2 ulp; one golden vector
+ * crosses the boundary: tests/golden/f32_full_96k_libm.npz (the reference with glibc's own libm,
+ * BASELINE config 3's preset) is reproduced word for word by the oracle and by the GPU.
  * The float-to-int casts saturate as on both MCUs (vcvt.s32.f32 / the RP2040 bootrom's
  * float2int_z); an x86 build of the same C gives INT_MIN instead — for Q28 the one place this
  * shows in normal operation is the limiter quotient (leveller.c:376), where "bit-exact" rests on
@@ -71,7 +77,11 @@ extern "C" {
  * (usb_audio.c:697-712), matrix mix (:766), leveller envelope and smoother (leveller.c:165-166, :200), crossfeed
  * (crossfeed.c:137-148) and the coefficient design functions.  Without the flag every multiply and add rounds on its own
  * (the source read literally, -ffp-contract=off).  Both contracts are pinned bit-for-bit to the reference compiled the
- * corresponding way (oracle/Makefile, tests/test_oracle_vs_fw.py); the fused one needs a third fewer vector instructions. */
+ * corresponding way (oracle/Makefile, tests/test_oracle_vs_fw.py); the fused one needs a third fewer vector instructions.
+ * PRECISELY what this contract is: "GCC 11, x86-64, -ffp-contract=fast -mfma with the vectorisers off: the GIMPLE-level contraction of
+ * the same source" — not "the Cortex-M33 binary".  That arm-none-eabi-gcc fuses the same pairs is read off GCC's target-independent
+ * tree pass (the .FMA / .FMS / .FNMA calls of -fdump-tree-optimized, listed in DESIGN.md section 5), not executed: the image has no ARM
+ * toolchain.  What north_star asks of the two contracts — within 1 ULP per stage of each other — is measured (profiles/r02_ulp_per_stage.md). */
 #define DSPI_FLOAT_CONTRACT_FMA 0x100
 #define DSPI_FLAVOR_RP2350_F32_FMA (DSPI_FLAVOR_RP2350_F32 | DSPI_FLOAT_CONTRACT_FMA)
 /* OR into the flavour of dspi_create: what the power-on models.  By default every stream is a device that boots for the FIRST time on an

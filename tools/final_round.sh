@@ -2,7 +2,7 @@
 # tools/final_round.sh <round tag> — the round's closing measurements in one gpurun call: the whole -m gpu suite, smoke(), the default
 # bench line (with the CPU baseline), every other bench configuration, the one-packet-per-call drop-in, small contexts, and the rocprofv3
 # summaries of every kernel (tools/prof_all.sh).  Everything lands under gpurun_out/final_<tag>/ (+ gpurun_out/profsum/), copied to profiles/ by hand.
-R=${1:-r04}
+R=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/final_$R; mkdir -p $O
 (time python -m pytest tests -m gpu -q 2>&1 | tail -8) > $O/gputest.log 2>&1
@@ -25,7 +25,7 @@ run pdm python bench.py --config pdm --out-layout tiled
 run spdif python bench.py --config spdif
 run i2s python bench.py --config i2s
 run blocks200_tiled python bench.py --out-layout tiled --blocks-per-step 200 --no-cpu-baseline --no-variants
-python tools/bench_realtime.py --calls 10000 --presets config3,config3_leveller_off,config2 --out $O/realtime.json > $O/realtime.log 2>&1
+python tools/bench_realtime.py --calls 30000 --presets config3,config3_leveller_off,config2 --out $O/realtime.json > $O/realtime.log 2>&1
 DSPI_Q28_LAYOUT=chain python tools/bench_realtime.py --calls 3000 --flavors q28 --out $O/realtime_q28_chain_kernel.json > $O/realtime_q28_chain_kernel.log 2>&1
 # the thin C host's node-level mode on the one GPU of this box: one context + feeder thread, the reduction through ncclCommInitAll / ncclAllReduce
 python -c "
@@ -40,5 +40,10 @@ python tools/bench_small_contexts.py > $O/small_contexts_leveller_on.jsonl 2>/de
 LEVELLER=0 python tools/bench_small_contexts.py > $O/small_contexts_leveller_off.jsonl 2>/dev/null
 SIZES=16,128,512,1024,2048,4096 PERSTREAM=1 python tools/bench_small_contexts.py > $O/small_contexts_per_stream_leveller_on.jsonl 2>/dev/null
 SIZES=512,1024,2048,4096 LEVELLER=0 PERSTREAM=1 python tools/bench_small_contexts.py > $O/small_contexts_per_stream_leveller_off.jsonl 2>/dev/null
+# round 6: the energy model behind roofline.energy_floor_j (-> profiles/power_model_<tag>.json + <tag>_power_model.md), config 2's calibration
+# kernel, the two-waves-per-SIMD arithmetic probe
+POWER_MODEL_JSON=$O/power_model.json python tools/ablate_power.py > $O/power_model.md 2>&1
+bash tools/probe/probe11_run.sh > $O/config2_calibration.md 2>&1
+(cd tools/probe && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o probe12 probe12.hip && ./probe12) > $O/probe12.md 2>&1
 bash tools/prof_all.sh $R > $O/prof_all.log 2>&1
 tail -3 $O/gputest.log; tail -2 $O/smoke.log; ls $O gpurun_out/profsum | head -80
