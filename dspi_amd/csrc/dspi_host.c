@@ -169,7 +169,7 @@ typedef struct {
     int rc; char err[200];
     double frames, seconds;
     int channels;
-    int numa_node, cpus_pinned; char pin_src[24];       /* the feeder thread's affinity */
+    int numa_node, cpus_pinned; char pin_src[48];       /* the feeder thread's affinity */
     double bytes_strict, bytes_resident;                /* algorithmic HBM bytes per frame of this shard's preset */
     uint32_t check_sum, check_words; int checked;       /* the last call's pair words of the shard's first stream */
 } Shard;
@@ -322,7 +322,7 @@ static void *shard_main(void *arg) {
                 char path[512];
                 if (h->rank == 0) snprintf(path, sizeof path, "%s", h->outp); else snprintf(path, sizeof path, "%s.dev%d", h->outp, h->rank);
                 FILE *f = fopen(path, "wb");
-                if (!f) { free(w); SHARD_FAIL("-o %s", path); }
+                if (!f) { free(w); SHARD_FAIL("-o %.150s", path); }
                 fwrite(w, 1, n, f); fclose(f);
             }
             free(w);
