@@ -440,7 +440,9 @@ def main():
                        "collective": "all_reduce(SUM) of the frames + all_reduce(MAX) of the elapsed time, 8 bytes each, then one all_gather of 12 doubles per rank (its times, its parity verdict and checked streams), all after the timed region (dspi_amd/shard.py)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist: dist.destroy_process_group()
+    if dist:
+        dist.barrier()      # (rank 0 has timed the CPU baseline meanwhile: every rank leaves the group together)
+        dist.destroy_process_group()
 
 
 def timed_steps(args, torch, dist, backend, dev, ctx, step, min_load_s=0.0):
