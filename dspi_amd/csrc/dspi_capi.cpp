@@ -21,6 +21,7 @@
 #include <thread>
 #include <xmmintrin.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include "../../include/dspi_detmath.h"
 
@@ -97,6 +98,9 @@ struct dspi_ctx {
     uint16_t *d_clip = nullptr; size_t d_clip_cap = 0;          // DSPI_OUT_CLIP_FLAGS on host buffers
     // small calls on host buffers (one packet per call, the firmware's own rhythm): a pinned host area the kernels read and write directly
     char *h_direct = nullptr; char *d_direct = nullptr; size_t direct_cap = 0;
+    // ... and a completion word of its own next to that area (round 6): the stream writes the call's sequence number there once the launches
+    // have ended (hipStreamWriteValue32) and the host polls MEMORY instead of calling into the runtime (hipStreamQuery) thousands of times
+    uint32_t *h_done = nullptr; uint32_t *d_done = nullptr; uint32_t direct_seq = 0; int direct_flag = -1;      // -1: untried, 0: not available / DSPI_DIRECT_POLL=query, 1: in use
     int32_t *d_spdif_words = nullptr; size_t d_spdif_words_cap = 0;      // DSPI_OUT_SPDIF on launches the latency layout does not serve: the chain's pair words of one row chunk
     // PDM sub output (dspi_pdm.hip): modulator state per stream, allocated on first use; staging for host buffers
     uint32_t *d_pdm = nullptr;
@@ -753,6 +757,7 @@ void dspi_destroy(dspi_ctx *c) {
                         (void *)c->d_pairs, (void *)c->d_sub, (void *)c->d_peaks, (void *)c->d_clip, (void *)c->d_spdif_words})
             if (p) (void)hipFree(p);
         if (c->h_direct) (void)hipHostFree(c->h_direct);
+        if (c->h_done) (void)hipHostFree(c->h_done);
         for (hipEvent_t e : c->pipe_events) (void)hipEventDestroy(e);
         if (c->hs_in) (void)hipStreamDestroy(c->hs_in);
         if (c->hs_out) (void)hipStreamDestroy(c->hs_out);
@@ -1238,14 +1243,43 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
         // How long: the audio time the call carries (a caller in the firmware's rhythm has exactly that long per call, and a wake-up from the
         // blocking wait — an interrupt, a scheduler pass — is the dropout-class outlier of BENCH_r05: one 10 ms call in 3 000), never less than
         // 300 us, never more than 50 ms; DSPI_DIRECT_SPIN_US (read at dspi_create) overrides it.
-        hipError_t q;
+        // What is polled (round 6): a word in pinned host memory that the stream itself sets to this call's sequence number behind the launches
+        // (hipStreamWriteValue32) — a load per poll, no call into the runtime while waiting; hipStreamQuery where that is not available
+        // (DSPI_DIRECT_POLL=query forces it).
+        if (c->direct_flag < 0) {
+            const char *e = getenv("DSPI_DIRECT_POLL");
+            c->direct_flag = 0;
+            if (!(e && !strcmp(e, "query"))) {
+                void *hp = nullptr, *dp = nullptr;
+                if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                    c->h_done = (uint32_t *)hp; c->d_done = (uint32_t *)dp; *c->h_done = 0u; c->direct_flag = 1;
+                } else { if (hp) (void)hipHostFree(hp); (void)hipGetLastError(); }
+            }
+        }
+        bool flagged = false;
+        if (c->direct_flag == 1) {
+            ++c->direct_seq;
+            if (hipStreamWriteValue32(c->hs, c->d_done, c->direct_seq, 0) == hipSuccess) flagged = true;
+            else { (void)hipGetLastError(); c->direct_flag = 0; }      // (this runtime / device cannot: the stream is polled from here on)
+        }
+        hipError_t q = hipSuccess;
         const auto spin_t0 = std::chrono::steady_clock::now();
         const uint64_t audio_us = (uint64_t)frames * 1000000u / 44100u;      // (the slowest rate the firmware runs: an upper bound of the packet's time)
         const auto budget = std::chrono::microseconds(c->direct_spin_us ? (uint64_t)c->direct_spin_us : std::min<uint64_t>(50000u, std::max<uint64_t>(300u, audio_us)));
         uint32_t polls = 0;
         bool fell_back = false;
-        while ((q = hipStreamQuery(c->hs)) == hipErrorNotReady) {
-            if ((++polls & 63u) == 0 && std::chrono::steady_clock::now() - spin_t0 > budget) { q = hipStreamSynchronize(c->hs); fell_back = true; break; }
+        if (flagged) {
+            volatile const uint32_t *done = c->h_done;
+            const uint32_t want = c->direct_seq;
+            while (*done != want) {
+                __builtin_ia32_pause();
+                if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - spin_t0 > budget) { q = hipStreamSynchronize(c->hs); fell_back = true; break; }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);      // the words the kernels wrote are read after the flag
+        } else {
+            while ((q = hipStreamQuery(c->hs)) == hipErrorNotReady) {
+                if ((++polls & 63u) == 0 && std::chrono::steady_clock::now() - spin_t0 > budget) { q = hipStreamSynchronize(c->hs); fell_back = true; break; }
+            }
         }
         {
             const auto t_end = std::chrono::steady_clock::now();

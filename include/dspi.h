@@ -66,7 +66,7 @@ extern "C" {
                               * dspi_debug_launch_plan, dspi_debug_image_count; 5: DSPI_OUT_ENABLED_ONLY, DSPI_OUT_I2S_SLOTS, DSPI_BOOT_POPULATED_FLASH, dspi_debug_launch_plan counts[5];
                               * 6: DSPI_OUT_SPDIF, dspi_spdif_block_pos; 7: dspi_out.clip_flags behind DSPI_OUT_CLIP_FLAGS, DSPI_OUT_SPDIF on every
                               * context, (additions only: a v6 caller's three-member dspi_out is never read past `peaks`);
-                              * 8: dspi_debug_direct_stats, dspi_debug_detmath, the direct path's polling budget = the call's own audio time (DSPI_DIRECT_SPIN_US) */
+                              * 8: dspi_debug_direct_stats, dspi_debug_detmath, the direct path polls a completion word for the call's own audio time (DSPI_DIRECT_SPIN_US, DSPI_DIRECT_POLL) */
 
 /* flavours: values equal the firmware's platform ids (config.h:269-270) */
 #define DSPI_FLAVOR_RP2040_Q28 0   /* 7 channels, 5 outputs, int32 Q28, 2048-sample delay lines */
@@ -299,9 +299,11 @@ int dspi_debug_launch_plan(dspi_ctx *ctx, uint32_t *counts, size_t n_counts);
  * forms; 2: log10f, 3: 10^a[i], 4: a[i]^b[i] in the forms the chain kernels use (step 1 + exception tables).  Tests compare all of them bit for
  * bit with the host build of the same header and with binary128. */
 int dspi_debug_detmath(dspi_ctx *ctx, int which, const float *a, const float *b, uint32_t n, float *out);
-/* Small calls on host buffers (one packet per call, usb_audio.c:1326-1332) poll the context's stream instead of sleeping on it: for the audio
+/* Small calls on host buffers (one packet per call, usb_audio.c:1326-1332) do not sleep on their stream: the stream writes the call's sequence
+ * number into a word of pinned host memory behind the launches (hipStreamWriteValue32) and the host polls that word — a load per poll, no call
+ * into the runtime while waiting (a hipStreamQuery was seen to block for 10 ms once in 240 000 calls: the dropout of BENCH_r05) — for the audio
  * time the call carries (frames at 44.1 kHz; at least 300 us, at most 50 ms; DSPI_DIRECT_SPIN_US, read at dspi_create, overrides), then the
- * blocking wait.  out[5] = {such calls so far, calls that reached the blocking wait, longest enqueue phase in ns (entry -> launches issued),
+ * blocking wait.  DSPI_DIRECT_POLL=query polls the stream instead (also the fallback where the write is not available).  out[5] = {such calls so far, calls that reached the blocking wait, longest enqueue phase in ns (entry -> launches issued),
  * longest wait phase in ns (these three over the calls after the context's first eight), the last call's polling budget in ns}.  tools/bench_realtime.py reports them next to the latency percentiles.
  * Returns 5 or a negative DSPI_E_*. */
 int dspi_debug_direct_stats(dspi_ctx *ctx, uint64_t *out, size_t n);

@@ -1,10 +1,17 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r06j; mkdir -p $O
-(time python -m pytest tests -m gpu -q -x 2>&1 | tail -12) > $O/gputest.log 2>&1
-bash tools/ab_bench.sh "libr05.so libdspi_mi355x.so" 3 > $O/ab_default.log 2>&1
-bash tools/ab_bench.sh "libr05.so libdspi_mi355x.so" 2 --out-layout tiled > $O/ab_tiled.log 2>&1
-bash tools/ab_bench.sh "libr05.so libdspi_mi355x.so" 2 --config perstream > $O/ab_perstream.log 2>&1
-bash tools/ab_bench.sh "libr05.so libdspi_mi355x.so" 2 --config perstream_eq --out-layout tiled > $O/ab_perstream_eq_tiled.log 2>&1
-bash tools/ab_bench.sh "libr05.so libdspi_mi355x.so" 2 --config 5 > $O/ab_config5.log 2>&1
-bash tools/ab_bench.sh "libr05.so libdspi_mi355x.so" 1 --config 2 > $O/ab_config2.log 2>&1
-tail -4 $O/gputest.log; for f in $O/ab_*.log; do echo $f; cat $f; done
+O=gpurun_out/r06l; mkdir -p $O
+for rep in 1 2 3 4; do
+  for mode in query flag; do
+    chk="--no-check"; [ $rep = 1 ] && chk=""
+    DSPI_DIRECT_POLL=$mode python tools/bench_realtime.py --calls 30000 --streams 1 $chk > $O/rt_${mode}_$rep.jsonl 2>&1
+  done
+done
+python - <<'PY'
+import json, glob
+for mode in ("query", "flag"):
+    for f in sorted(glob.glob(f"gpurun_out/r06l/rt_{mode}_*.jsonl")):
+        for l in open(f):
+            if l.startswith("{"):
+                r = json.loads(l)
+                print(mode, r["flavor"], "p50 %.1f p99 %.1f p99.9 %.1f p99.99 %.1f max %.1f over %d" % (r["p50_us"], r["p99_us"], r["p99_9_us"], r["p99_99_us"], r["max_us"], r["n_over_packet"]), r["direct_path"], r.get("parity", "")[:12])
+PY
