@@ -140,6 +140,33 @@ def test_latency_layout(flavor, fs, B, depth, monkeypatch):
     d.close()
 
 
+@pytest.mark.parametrize("flavor", (W.F32_FMA, 0), ids=("f32fma", "q28"))
+def test_one_packet_calls_both_ways_of_waiting(flavor, monkeypatch):
+    """Small calls on host buffers wait for their launches by polling a completion word the stream writes behind them (hipStreamWriteValue32,
+    round 6) or, with DSPI_DIRECT_POLL=query, the stream itself (rounds 4-5, and the fallback): the same words either way, call after call,
+    equal to the oracle; the library's own record says which calls it counted (dspi_debug_direct_stats)."""
+    fl = int(flavor)
+    fs, B, calls, S = (96000, 96, 60, 5) if fl else (48000, 48, 60, 5)
+    blob = WL.full_chain_blob(fl)
+    pcm = WL.synth_pcm16(S, B * calls, fs)
+    got = {}
+    for mode in ("flag", "query"):
+        if mode == "query": monkeypatch.setenv("DSPI_DIRECT_POLL", "query")
+        else: monkeypatch.delenv("DSPI_DIRECT_POLL", raising=False)
+        monkeypatch.delenv("DSPI_F32_LAYOUT", raising=False)
+        d = Dspi(flavor, S, device=0); d.set_rate(fs); d.set_volume(-20 * 256); assert d.load_bulk(blob) == 0
+        outs = [d.process_host(np.ascontiguousarray(pcm[:, c * B:(c + 1) * B]), 1, B) for c in range(calls)]
+        st = d.direct_stats()
+        assert st["calls"] == calls and st["spin_budget_us"] >= 300.0, st
+        got[mode] = (np.concatenate([o[0] for o in outs], axis=2), np.concatenate([o[1] for o in outs], axis=1), np.concatenate([o[2] for o in outs], axis=1))
+        d.close()
+    for a, b in zip(got["flag"], got["query"]): assert np.array_equal(a, b)
+    for s in (0, S - 1):
+        o = Oracle(flavor, detmath=True); o.set_rate(fs); o.set_volume(-20 * 256); assert o.load_bulk(blob) == 0
+        rp, rs, rk, _ = o.process(pcm[s], calls, B)
+        assert np.array_equal(rp, got["flag"][0][s]) and np.array_equal(rs, got["flag"][1][s]) and np.array_equal(rk, got["flag"][2][s]), s
+
+
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA), ids=("canonical", "fma"))
 @pytest.mark.parametrize("fs,B", [(48000, 48), (44100, 45), (96000, 192), (48000, 7)])
 def test_latency_layout_lines_of_disabled_outputs(flavor, fs, B, monkeypatch):
