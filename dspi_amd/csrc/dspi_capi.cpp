@@ -1237,12 +1237,12 @@ int dspi_process(dspi_ctx *c, const void *pcm_in, int bit_depth, uint32_t n_bloc
     if (direct) {
         if ((rc = launch_rows(0, c->n_wg))) return rc;
         if (clip_out && (rc = gather_clip(reinterpret_cast<uint16_t *>(c->d_direct + off_clip)))) return rc;
-        // the launches take tens of microseconds: polling the stream answers within a microsecond of their end, a blocking wait adds a wake-up
-        // — but only for as long as such launches take: after ~300 us of polling the call falls back to the blocking wait (a hung queue, or a
-        // host running many contexts, must not pin a core)
-        // How long: the audio time the call carries (a caller in the firmware's rhythm has exactly that long per call, and a wake-up from the
-        // blocking wait — an interrupt, a scheduler pass — is the dropout-class outlier of BENCH_r05: one 10 ms call in 3 000), never less than
-        // 300 us, never more than 50 ms; DSPI_DIRECT_SPIN_US (read at dspi_create) overrides it.
+        // the launches take tens of microseconds: polling answers within a microsecond of their end, a blocking wait adds a wake-up — but only
+        // for as long as such launches can take: past the budget the call falls back to the blocking wait (a hung queue, or a host running
+        // many contexts, must not pin a core).  The budget: the audio time the call carries (a caller in the firmware's rhythm has exactly
+        // that long per call), never less than 300 us, never more than 50 ms; DSPI_DIRECT_SPIN_US (read at dspi_create) overrides it.
+        // (The rare 0.5-10 ms calls — BENCH_r05 had one — are not this loop's: its clock check does not fire during them, the thread is off
+        //  its core; profiles/r06_realtime_polling.md.)
         // What is polled (round 6): a word in pinned host memory that the stream itself sets to this call's sequence number behind the launches
         // (hipStreamWriteValue32) — a load per poll, no call into the runtime while waiting; hipStreamQuery where that is not available
         // (DSPI_DIRECT_POLL=query forces it).

@@ -98,9 +98,9 @@ def test_dspi_host_node_mode_through_rccl(tmp_path, flavor, scaling):
 
 def test_one_packet_calls_have_no_dropout_class_outliers(tmp_path):
     """the driver's run saw one 10 ms call among 3 000 one-packet calls.  10 000 calls per flavour, steady state: no call may
-    take longer than 500 us (the packet carries 1 000 us of audio), and none may have reached the blocking wait.  Two retries: the outlier that
-    was found (a hipStreamQuery blocking for 10 ms, ~1 call in 10^5) is gone with the completion word the host now polls, but a box's interrupt
-    storm is not this library's to fix — three failures in a row are."""
+    take longer than 500 us (the packet carries 1 000 us of audio), and none may have reached the blocking wait.  Two retries: the outliers that
+    were located (the calling thread off its core for 0.5-10 ms, ~1 call in 10^5, in either way of waiting) are the box's scheduler, not this
+    library's to fix — three failures in a row would be something else."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_realtime
