@@ -305,7 +305,8 @@ int dspi_debug_detmath(dspi_ctx *ctx, int which, const float *a, const float *b,
  * least 300 us, at most 50 ms; DSPI_DIRECT_SPIN_US, read at dspi_create, overrides), then the blocking wait.  DSPI_DIRECT_POLL=query polls the
  * stream instead (also the fallback where the write is not available).  What neither way of waiting removes: about one call in 10^5 during
  * which the calling thread itself does not run for 0.5 - 10 ms (the wait phase is long, yet the loop's own clock check never fired): the
- * host's scheduler, for a caller to address with a real-time priority or an isolated core. */  out[5] = {such calls so far, calls that reached the blocking wait, longest enqueue phase in ns (entry -> launches issued),
+ * host's scheduler, for a caller to address with a real-time priority or an isolated core.
+ * out[5] = {such calls so far, calls that reached the blocking wait, longest enqueue phase in ns (entry -> launches issued),
  * longest wait phase in ns (these three over the calls after the context's first eight), the last call's polling budget in ns}.  tools/bench_realtime.py reports them next to the latency percentiles.
  * Returns 5 or a negative DSPI_E_*. */
 int dspi_debug_direct_stats(dspi_ctx *ctx, uint64_t *out, size_t n);
