@@ -102,6 +102,8 @@ def test_one_packet_calls_have_no_dropout_class_outliers(tmp_path):
     were located (the calling thread off its core for 0.5-10 ms, ~1 call in 10^5, in either way of waiting) are the box's scheduler, not this
     library's to fix — three failures in a row would be something else."""
     import sys
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("a latency bound needs the GPU to itself: under pytest-xdist the other workers' kernels share it (run this file serially)")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_realtime
     for fname, flavor, fs, B in (("f32fma", W.F32_FMA, 96000, 96), ("q28", 0, 48000, 48)):
