@@ -1,11 +1,7 @@
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r06z; mkdir -p $O
-(python -m pytest tests -m gpu -q -x -n 4 2>&1 | tail -5) > $O/gputest.log 2>&1
-python tools/bench_realtime.py --calls 20000 --streams 1,16,128 --flavors f32fma --presets config3,config3_leveller_off,config2 --no-check > $O/rt.jsonl 2>&1
-python - <<'PY'
-import json
-for l in open("gpurun_out/r06z/rt.jsonl"):
-    if l.startswith("{"):
-        r = json.loads(l); print(r["preset"], r["streams"], "p50 %.1f p99 %.1f max %.1f" % (r["p50_us"], r["p99_us"], r["max_us"]))
-PY
-tail -3 $O/gputest.log
+#!/bin/bash
+# ad hoc batch of the round (run via gpurun): probe13 + same-box A/B of latency-layout builds on configs 2 / 2b
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out/r06r
+(cd tools/probe && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o probe13 probe13.hip && timeout 300 ./probe13) > gpurun_out/r06r/probe13.txt 2>&1
+LIBS="${LIBS:-libpre_exp.so libdspi_mi355x.so}"
+for c in 2 2b; do echo "== config $c"; bash tools/ab_bench.sh "$LIBS" 2 --config $c --no-side-runs; done > gpurun_out/r06r/ab.txt 2>&1
+cat gpurun_out/r06r/probe13.txt gpurun_out/r06r/ab.txt
