@@ -1259,6 +1259,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void chain_kernel(KArgs a
         int32_t env_end = 0;
         bool decide = false;
         uint32_t kd = 0;
+        WT_DECL;
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (decide) {      // gain decision of packet kd (leveller.c:304-334): pass 1 of both channels ended in the previous step
                 const bool lev_on = (PL ? img_l->flags : img->flags) & IF_LEVELLER_ON;
@@ -1298,8 +1299,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void chain_kernel(KArgs a
                 }
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
+            WT_BEFORE_BARRIER;
             lds_barrier();
+            WT_AFTER_BARRIER;
         }
+        WT_FINISH(0);
         gs[(sm.xfeed + 0) * ROW] = (uint32_t)m.lpL; gs[(sm.xfeed + 1) * ROW] = (uint32_t)m.lpR;
         gs[(sm.xfeed + 2) * ROW] = (uint32_t)m.apL; gs[(sm.xfeed + 3) * ROW] = (uint32_t)m.apR;
         gs[(sm.lev + 0) * ROW] = (uint32_t)m.env_l;
@@ -1322,6 +1326,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void chain_kernel(KArgs a
         int32_t env_r = right ? (int32_t)gs[(sm.lev + 1) * ROW] : 0;
         uint32_t rp1 = gs[sm.ring_pos * ROW] & (kRingLen - 1);
         uint32_t kq = 0, cq = 0, k1 = 0, c1 = 0;
+        WT_DECL;
         for (uint32_t st = 0; st < g.steps; ++st) {
             if (right && st < g.items) {
                 if (TAIL && (c1 + 1) * T > g.B) {
@@ -1346,8 +1351,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void chain_kernel(KArgs a
                 }
                 if (++cq == g.cpb) { cq = 0; ++kq; }
             }
+            WT_BEFORE_BARRIER;
             lds_barrier();
+            WT_AFTER_BARRIER;
         }
+        WT_FINISH(role);
         if (role == 1) {
             gs[sm.widx * ROW] = s.widx;
             gs[(sm.mute + 0) * ROW] = s.loading; gs[(sm.mute + 1) * ROW] = s.counter; gs[(sm.mute + 2) * ROW] = as_u(s.smooth);
