@@ -7,7 +7,7 @@
 //   p9_wr16_lines               16-byte stores, one 128-byte line per lane, eight consecutive stores fill the line (the direct
 //                               pair-line pattern of a wave that holds both sides of an S/PDIF pair: 64 lines per store instruction)
 //   p9_wr4_stride8              4-byte stores at an 8-byte stride (one side of a pair written in place: every line half-filled)
-// Run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes); tools/probe/probe9_summary.py divides the counters
+// Run under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes): tools/probe/probe9_run.sh divides the counters
 // by the known bytes.  The program also prints each kernel's own GB/s (hipEvents).
 // Build: hipcc --offload-arch=gfx950 -O3 -o probe9 probe9.hip
 #include <hip/hip_runtime.h>
