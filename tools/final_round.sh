@@ -7,6 +7,15 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/final_$R; mkdir -p $O
 (time python -m pytest tests -m gpu -q 2>&1 | tail -8) > $O/gputest.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" >> $O/smoke.log
+# (first, so that every bench line below reads counter profiles and an energy model taken from THIS library: bench.py marks older ones stale)
+# round 6: the energy model behind roofline.energy_floor_j (-> profiles/power_model_<tag>.json + <tag>_power_model.md), config 2's calibration
+# kernel, the two-waves-per-SIMD arithmetic probe
+POWER_MODEL_JSON=$O/power_model.json python tools/ablate_power.py > $O/power_model.md 2>&1
+bash tools/probe/probe11_run.sh > $O/config2_calibration.md 2>&1
+(cd tools/probe && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o probe12 probe12.hip && ./probe12) > $O/probe12.md 2>&1
+bash tools/prof_all.sh $R > $O/prof_all.log 2>&1
+cp gpurun_out/profsum/${R}[a-q]_summary.md gpurun_out/profsum/traffic_${R}[a-q].json profiles/ 2>/dev/null
+[ -f $O/power_model.json ] && cp $O/power_model.json profiles/power_model_$R.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 200 --no-cpu-baseline --no-variants > $O/bench_steps200.json 2>/dev/null
 b() { local name=$1; shift; env "$@" > /dev/null 2>&1; }
@@ -40,10 +49,4 @@ python tools/bench_small_contexts.py > $O/small_contexts_leveller_on.jsonl 2>/de
 LEVELLER=0 python tools/bench_small_contexts.py > $O/small_contexts_leveller_off.jsonl 2>/dev/null
 SIZES=16,128,512,1024,2048,4096 PERSTREAM=1 python tools/bench_small_contexts.py > $O/small_contexts_per_stream_leveller_on.jsonl 2>/dev/null
 SIZES=512,1024,2048,4096 LEVELLER=0 PERSTREAM=1 python tools/bench_small_contexts.py > $O/small_contexts_per_stream_leveller_off.jsonl 2>/dev/null
-# round 6: the energy model behind roofline.energy_floor_j (-> profiles/power_model_<tag>.json + <tag>_power_model.md), config 2's calibration
-# kernel, the two-waves-per-SIMD arithmetic probe
-POWER_MODEL_JSON=$O/power_model.json python tools/ablate_power.py > $O/power_model.md 2>&1
-bash tools/probe/probe11_run.sh > $O/config2_calibration.md 2>&1
-(cd tools/probe && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o probe12 probe12.hip && ./probe12) > $O/probe12.md 2>&1
-bash tools/prof_all.sh $R > $O/prof_all.log 2>&1
 tail -3 $O/gputest.log; tail -2 $O/smoke.log; ls $O gpurun_out/profsum | head -80
