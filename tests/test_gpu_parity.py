@@ -1722,3 +1722,46 @@ def test_per_band_taps_both_contracts():
                     if peak > 0:
                         assert float(np.abs(taps[b + 1] - other[b]).max()) <= 2.0 * float(np.spacing(np.float32(peak))), (ch, b)
         d.close()
+
+
+@pytest.mark.parametrize("flavor", FLAVORS_WITH_KERNEL)
+def test_refused_calls_leave_the_context_as_it_was(flavor):
+    """dspi_process refuses what process_audio_packet could never be handed — no buffer, a packet longer than the firmware's largest
+    (usb_audio.c:273-276, :588: 192 frames), a word size that is neither of the two alt settings (usb_descriptors.c), zero packets, flag bits
+    this ABI does not define, subframes in a layout they do not have — with DSPI_E_INVAL and WITHOUT touching the streams: the calls
+    around the refused ones give the oracle's words as if those had never been made (first-boot mute, filter state, delay lines, meters)."""
+    import ctypes as C
+    from dspi_amd.host import _Out, OUT_TILED, OUT_SPDIF
+    S, fs, B, blocks = 3, 48000, 48, 6
+    blob = WL.full_chain_blob(flavor)
+    d = Dspi(flavor, S, device=0)
+    assert d.set_rate(fs) == 0
+    d.set_volume(-20 * 256)
+    assert d.load_bulk(blob) == 0
+    pcm = WL.synth_pcm16(S, B * blocks, fs)
+    half = blocks // 2
+    first = d.process_host(np.ascontiguousarray(pcm[:, :half * B]), half, B, 16)
+    F = half * B
+    pairs = np.zeros((S, d.P, F, 4), dtype=np.uint32); sub = np.zeros((S, F), dtype=np.int32); peaks = np.zeros((S, half, d.C), dtype=np.uint16)
+    out = _Out(pairs.ctypes.data, sub.ctypes.data, peaks.ctypes.data, None)
+    nxt = np.ascontiguousarray(pcm[:, half * B:])
+    E_INVAL = -10
+    call = lambda pcm_ptr, depth, nb, bl, o, fl: d.L.dspi_process(d.h, pcm_ptr, depth, nb, bl, o, fl)
+    assert call(None, 16, half, B, C.byref(out), 0) == E_INVAL                       # no input
+    assert call(nxt.ctypes.data, 16, half, B, None, 0) == E_INVAL                    # no dspi_out
+    assert call(nxt.ctypes.data, 20, half, B, C.byref(out), 0) == E_INVAL            # neither 16- nor 24-bit
+    assert call(nxt.ctypes.data, 16, 0, B, C.byref(out), 0) == E_INVAL               # no packets
+    assert call(nxt.ctypes.data, 16, half, 0, C.byref(out), 0) == E_INVAL            # empty packets
+    assert call(nxt.ctypes.data, 16, 1, 193, C.byref(out), 0) == E_INVAL             # longer than the firmware's largest packet
+    assert call(nxt.ctypes.data, 16, half, B, C.byref(out), 1 << 30) == E_INVAL      # an undefined flag bit
+    assert call(nxt.ctypes.data, 16, half, B, C.byref(out), OUT_SPDIF | OUT_TILED) == E_INVAL
+    assert b"DSPI_OUT_SPDIF" in d.L.dspi_last_error(d.h)
+    assert not pairs.any() and not sub.any() and not peaks.any()                     # nothing was written either
+    second = d.process_host(nxt, half, B, 16)
+    for s in range(S):
+        o2 = Oracle(flavor, detmath=True); assert o2.set_rate(fs) == 0; o2.set_volume(-20 * 256); assert o2.load_bulk(blob) == 0
+        rp, rs, rk, _ = o2.process(pcm[s], blocks, B, 16)
+        got_p = np.concatenate([first[0][s], second[0][s]], axis=1); got_s = np.concatenate([first[1][s], second[1][s]]); got_k = np.concatenate([first[2][s], second[2][s]])
+        assert np.array_equal(got_p, rp), f"stream {s}: pair words differ after refused calls"
+        assert np.array_equal(got_s, rs) and np.array_equal(got_k, rk)
+    d.close()
