@@ -12,6 +12,13 @@ from dspi_amd import wire as W
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a GPU")]
 
+def _seeds(default):
+    """seeds of one test: DSPI_FUZZ_SEEDS of them (default: a handful) starting at DSPI_FUZZ_SEED0 (default 0) — a longer or a FRESH sweep is
+    `DSPI_FUZZ_SEED0=400 DSPI_FUZZ_SEEDS=400 pytest tests/test_gpu_fuzz.py -m gpu`"""
+    s0 = int(os.environ.get("DSPI_FUZZ_SEED0", 0))
+    return range(s0, s0 + int(os.environ.get("DSPI_FUZZ_SEEDS", default)))
+
+
 RATES = [(44100, (44, 45)), (48000, (48,)), (96000, (96,))]
 
 
@@ -64,7 +71,7 @@ def random_blob(rng, flavor, fs):
 
 @pytest.mark.all_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
-@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 12))))      # more seeds: DSPI_FUZZ_SEEDS=200 pytest ...
+@pytest.mark.parametrize("seed", _seeds(12))      # more seeds: DSPI_FUZZ_SEEDS=200 pytest ...
 def test_random_presets(flavor, seed):
     from test_gpu_parity import compare
     rng = np.random.default_rng(1000 * flavor + seed)
@@ -116,7 +123,7 @@ def random_request(rng, flavor, fs):
 
 @pytest.mark.all_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
-@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 6))))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_random_request_sequences(flavor, seed):
     """Random vendor SET requests between launches — to every stream or to one — with their side effects on audio state
     (filter-path resets, crossfeed / leveller resets, delay changes, mutes), host volume / mute changes, and a sample-rate
@@ -172,7 +179,7 @@ def test_random_request_sequences(flavor, seed):
 
 @pytest.mark.all_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
-@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 6))))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_output_pointer_and_layout_combinations(flavor, seed):
     """dspi_process with any subset of {pairs, sub, peaks} requested, in either layout, 16- or 24-bit input, must hand back
     exactly what a full stream-major call returns (one context per variant, same input, two launches each)."""
@@ -205,7 +212,7 @@ def test_output_pointer_and_layout_combinations(flavor, seed):
 
 
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA, 0))
-@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 4))))
+@pytest.mark.parametrize("seed", _seeds(4))
 def test_random_preset_per_stream(flavor, seed):
     """Every stream loads its own random blob: band kinds, flags, delays and leveller / crossfeed / loudness settings all
     differ from lane to lane inside one workgroup (per-lane parameter kernels, SIMT divergence on the band forms); a few
@@ -241,7 +248,7 @@ def test_random_preset_per_stream(flavor, seed):
 
 @pytest.mark.all_layouts
 @pytest.mark.parametrize("flavor", (1, W.F32_FMA))
-@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPI_FUZZ_SEEDS", 8))))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_random_numbers_one_random_structure(flavor, seed):
     """One random preset for everybody, then every stream changes NUMBERS in it — band gains and Q at the band's own type and frequency,
     preamps, master volume, output gains, the gains of routed crosspoints, leveller amount / speed / max gain / gate, crossfeed — so that
