@@ -4,7 +4,7 @@
 R=${1:-r06}
 cd "$(dirname "$0")/.."
 O=gpurun_out/final_$R
-cp gpurun_out/profsum/${R}[a-q]_summary.md gpurun_out/profsum/traffic_${R}[a-q].json profiles/
+cp gpurun_out/profsum/${R}[a-r]_summary.md gpurun_out/profsum/traffic_${R}[a-r].json profiles/
 for f in default steps200 blocks200_tiled config3_512streams config_2 config_2b config_5 config_5_64k config_5_1024streams perstream perstream_eq perstream_eq_every_band pdm spdif i2s; do
   cp $O/bench_$f.json profiles/bench_${R}_$f.json
 done

@@ -40,6 +40,7 @@ def headline():
             ("3, FMA, tiled", "a", "`chain_kernel_pk` (words written ahead)"),
             ("3, canonical, tiled", "c", ""), ("3, canonical, stream-major", "d", ""),
             ("**2** (`--config 2`, `DSPI_OUT_ENABLED_ONLY`)", "l", "`chain_kernel_skew` (section 4.3)"),
+            ("2b (`--config 2b`: every band a biquad)", "r", ""),
             ("2 forced onto the packed kernel", "m", "`chain_kernel_pk`"),
             ("3's preset on 512 streams", "p", "`chain_kernel_skew_lev`"),
             ("5, Q28, 16 384 streams", "e", "`chain_kernel<0,…,7>`"), ("5 at 65 536 streams", "k", "`chain_kernel<0,…,4>`"),

@@ -14,7 +14,7 @@ POWER_MODEL_JSON=$O/power_model.json python tools/ablate_power.py > $O/power_mod
 bash tools/probe/probe11_run.sh > $O/config2_calibration.md 2>&1
 (cd tools/probe && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o probe12 probe12.hip && ./probe12) > $O/probe12.md 2>&1
 bash tools/prof_all.sh $R > $O/prof_all.log 2>&1
-cp gpurun_out/profsum/${R}[a-q]_summary.md gpurun_out/profsum/traffic_${R}[a-q].json profiles/ 2>/dev/null
+cp gpurun_out/profsum/${R}[a-r]_summary.md gpurun_out/profsum/traffic_${R}[a-r].json profiles/ 2>/dev/null
 [ -f $O/power_model.json ] && cp $O/power_model.json profiles/power_model_$R.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 200 --no-cpu-baseline --no-variants > $O/bench_steps200.json 2>/dev/null

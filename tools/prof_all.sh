@@ -16,6 +16,7 @@ run e "--config 5" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=chain5 STREAMS=
 run k "--config 5 --streams 65536" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=chain5_64k STREAMS=65536 BLOCK_LEN=48 ALGO_BYTES=56 KERNEL_LIKE="%chain_kernel<0%" NOTE="Q28 7-channel chain at 65 536 streams (two workgroups per CU)"
 run q "--config 5 --streams 1024" CONTRACT=integer OUT_LAYOUT=stream KERNEL_KEY=chain5_1024 STREAMS=1024 BLOCK_LEN=48 ALGO_BYTES=56 KERNEL_LIKE="%chain_kernel_q28_lat%" NOTE="Q28 chain on 1 024 streams: the integer flavour's latency layout (dspi_chain_q28_lat.inc: one stream per workgroup, one lane per (channel, stage))"
 run l "--config 2" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain2 STREAMS=4096 BLOCK_LEN=48 PACKETS_PER_LAUNCH=2000 ALGO_BYTES=12 KERNEL_LIKE="%chain_kernel_skew%" NOTE="BASELINE config 2: 4 096 streams, master PEQ only, 2 000 packets per launch — the latency layout (dspi_chain_skew.inc), DSPI_OUT_ENABLED_ONLY"
+run r "--config 2b" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain2b STREAMS=4096 BLOCK_LEN=48 PACKETS_PER_LAUNCH=2000 ALGO_BYTES=12 KERNEL_LIKE="%chain_kernel_skew%" NOTE="BASELINE config 2b (config 2 with every band a biquad): 4 096 streams, master PEQ only, 2 000 packets per launch — the latency layout (dspi_chain_skew.inc), DSPI_OUT_ENABLED_ONLY"
 run m "--config 2" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain2_packed STREAMS=4096 BLOCK_LEN=48 PACKETS_PER_LAUNCH=2000 ALGO_BYTES=12 KERNEL_LIKE="%chain_kernel_pk%" DSPI_F32_LAYOUT=packed NOTE="BASELINE config 2 forced onto the packed kernel (DSPI_F32_LAYOUT=packed): the round-2 path, for comparison"
 run p "--config 3 --streams 512" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=chain3_512 STREAMS=512 KERNEL_LIKE="%chain_kernel_skew_lev%" NOTE="BASELINE config 3's preset on 512 streams: the latency layout's third shape (dspi_chain_skew_lev.inc: leveller on, output rows, rings between the groups)"
 run f "--config perstream" CONTRACT=fma OUT_LAYOUT=stream KERNEL_KEY=perstream KERNEL_LIKE="%chain_kernel_pk%" NOTE="65 536 distinct presets with identical filters (preamp per stream): packed kernel, per-lane values, shared band coefficients; stream-major words"
