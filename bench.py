@@ -166,8 +166,14 @@ def cpu_baseline(flavor: int, fs: int, block_len: int, blob, channels: int, fma:
     import orclib
     from dspi_amd import workloads as WL
 
-    if orclib.ref_available(flavor, "fw", fma): ref, kind, how = "fw", "reference", "the reference's process_audio_packet + leaf sources compiled in place (oracle/_ref/libref_fw_*)"
-    elif orclib.ref_available(flavor, "ref", fma): ref, kind, how = True, "reference", "reference leaf C (oracle/_ref) under the restated orchestrator"
+    # DSPI_CPU_BASELINE=leaf: time the strict reference build (the leaf sources alone, no stand-in for anything) under the restated packet loop
+    # instead of the firmware build, whose usb_audio.c compiles over stand-ins for the un-vendored pico-sdk's headers
+    want = os.environ.get("DSPI_CPU_BASELINE", "fw")
+    stand_ins = None
+    if want == "fw" and orclib.ref_available(flavor, "fw", fma):
+        ref, kind, how = "fw", "reference", "the reference's process_audio_packet + leaf sources compiled in place (oracle/_ref/libref_fw_*)"
+        stand_ins = "usb_audio.c includes pico-sdk headers (un-vendored submodule): compiled over oracle/ref_stub_sdk (types, attribute macros, hardware entry points; no DSP code); DSPI_CPU_BASELINE=leaf times the leaf sources alone"
+    elif want in ("fw", "leaf") and orclib.ref_available(flavor, "ref", fma): ref, kind, how = True, "reference", "reference leaf C (oracle/_ref) under the restated orchestrator"
     else: ref, kind, how = False, "port", "oracle restatement"
     cores = os.cpu_count() or 1
     blocks = max(1, int(0.25 * fs / block_len))                     # 0.25 s of audio per call
@@ -203,6 +209,7 @@ def cpu_baseline(flavor: int, fs: int, block_len: int, blob, channels: int, fma:
                   f"{'-ffp-contract=fast (FMA), ' if fma else '-ffp-contract=off, '}FTZ|DAZ)",
         "frames_per_s": fps, "frames_per_s_min_max": [rates[0], rates[-1]],
         "single_core_frames_per_s": single, "single_core_realtime_x": single / fs,
+        "stand_ins": stand_ins,
     }
 
 
