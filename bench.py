@@ -157,22 +157,23 @@ class PowerSampler:
 # CPU baseline (rank 0, N = 1 only)
 # ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(flavor: int, fs: int, block_len: int, blob, channels: int, fma: bool, vol: int, what: str, budget_s: float = 25.0):
-    """The reference C path timed on this box's host cores.  Preference: the firmware build (the reference's own
-    process_audio_packet + leaf sources compiled in place, oracle/ref_fw.c; one private library copy per thread because the
-    firmware keeps its state in globals), else oracle/_ref (reference leaf sources under the restated orchestrator), else the
-    restatement ("port").  Protocol: CLOCK_MONOTONIC around >= 5 s of work, median of 5 — all host threads,
+    """The reference C path timed on this box's host cores.  Default: oracle/_ref's leaf build (the reference's leaf sources compiled
+    unmodified, under the restated orchestrator); DSPI_CPU_BASELINE=fw: the firmware build (the reference's own process_audio_packet +
+    leaf sources compiled in place over SDK stand-ins, oracle/ref_fw.c; one private library copy per thread because the firmware keeps its
+    state in globals); without oracle/_ref the restatement ("port").  Protocol: CLOCK_MONOTONIC around >= 5 s of work, median of 5 — all host threads,
     one independent stream each — and 5 x 1 s for the single-core figure; gcc -O3 -march=x86-64-v3, FTZ|DAZ."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
     from dspi_amd import workloads as WL
 
-    # DSPI_CPU_BASELINE=leaf: time the strict reference build (the leaf sources alone, no stand-in for anything) under the restated packet loop
-    # instead of the firmware build, whose usb_audio.c compiles over stand-ins for the un-vendored pico-sdk's headers (DESIGN.md section 5)
-    want = os.environ.get("DSPI_CPU_BASELINE", "fw")
+    # Default: the strict reference build (the leaf sources alone, compiled unmodified, no stand-in for anything) under the restated packet loop.
+    # DSPI_CPU_BASELINE=fw times the firmware build instead — the reference's own process_audio_packet, but its usb_audio.c compiles over
+    # stand-ins for the un-vendored pico-sdk's headers, which this task's rules do not accept as a reference build (DESIGN.md section 5)
+    want = os.environ.get("DSPI_CPU_BASELINE", "leaf")
     stand_ins = None
     if want == "fw" and orclib.ref_available(flavor, "fw", fma):
         ref, kind, how = "fw", "reference", "the reference's process_audio_packet + leaf sources compiled in place (oracle/_ref/libref_fw_*)"
-        stand_ins = "usb_audio.c includes pico-sdk headers (un-vendored submodule): compiled over oracle/ref_stub_sdk (types, attribute macros, hardware entry points; no DSP code); DSPI_CPU_BASELINE=leaf times the leaf sources alone"
+        stand_ins = "usb_audio.c includes pico-sdk headers (un-vendored submodule): compiled over oracle/ref_stub_sdk (types, attribute macros, hardware entry points; no DSP code); the default (DSPI_CPU_BASELINE=leaf) times the leaf sources alone"
     elif want in ("fw", "leaf") and orclib.ref_available(flavor, "ref", fma): ref, kind, how = True, "reference", "reference leaf C (oracle/_ref) under the restated orchestrator"
     else: ref, kind, how = False, "port", "oracle restatement"
     cores = os.cpu_count() or 1
