@@ -899,16 +899,30 @@ def test_tiled_output_layout(flavor):
 @pytest.mark.both_layouts
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_golden_fixtures_on_gpu(path):
-    """Vectors generated from the reference's own leaf sources (tests/golden/make_golden.py).  Skipped: the glibc-libm vector
-    whenever it would differ from detmath, and the one Q28 vector that encodes the x86 cast artefact (see test_oracle_golden)."""
+    """Vectors generated from the reference's own leaf sources (tests/golden/make_golden.py).  The one Q28 vector that encodes the x86 cast
+    artefact (see test_oracle_golden) is held to the golden up to the frame where the artefact starts, and to the oracle throughout."""
     g = np.load(path)
-    if "q28_full_48k_detmath" in path:
-        pytest.skip("golden encodes the x86 INT_MIN cast artefact of the reference build; GPU follows the firmware (saturating)")
     flavor = int(g["flavor"])
     d = Dspi(flavor, 1, device=0, fma=bool(int(g["fma"])) if "fma" in g else False)      # f32fma_*: the reference compiled with GCC's contraction
     d.set_rate(int(g["fs"])); d.set_volume(int(g["volume"])); assert d.load_bulk(g["blob"].tobytes()) == 0
     data = g["pcm"][None]
     pairs, sub, peaks = d.process_host(np.ascontiguousarray(data), int(g["blocks"]), int(g["block_len"]), int(g["bit_depth"]))
+    if "q28_full_48k_detmath" in path:
+        # This vector drives the Q28 limiter's cast out of range (leveller.c:376) from frame 497 on, where the reference's x86 build yields
+        # INT_MIN and the MCUs saturate (tests/test_oracle_golden.py::test_q28_limiter_cast_is_the_documented_divergence): its CRCs hold the
+        # x86 artefact.  What the reference's object code pins here is everything BEFORE that frame — the golden's first 96 frames of words
+        # and its first ten packets of meters, stored as they came out of the reference —; the whole vector is held to the firmware's
+        # (saturating) semantics through the oracle.
+        assert np.array_equal(pairs[0][:, :96], g["pairs_head"]) and np.array_equal(sub[0][:96], g["sub_head"])
+        assert np.array_equal(peaks[0][:10], g["peaks"][:10])
+        o = Oracle(flavor, detmath=True)
+        assert o.set_rate(int(g["fs"])) == 0
+        o.set_volume(int(g["volume"])); assert o.load_bulk(g["blob"].tobytes()) == 0
+        rp, rs, rk, _ = o.process(g["pcm"], int(g["blocks"]), int(g["block_len"]), int(g["bit_depth"]))
+        assert np.array_equal(pairs[0], rp) and np.array_equal(sub[0], rs) and np.array_equal(peaks[0], rk)
+        assert not np.array_equal(pairs[0][:, -96:], g["pairs_tail"])      # (and the tail is where the two part ways)
+        d.close()
+        return
     crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
     assert crc(pairs[0]) == int(g["pairs_crc"]) and crc(sub[0]) == int(g["sub_crc"]) and crc(peaks[0]) == int(g["peaks_crc"])
     assert list(d.status(0)) == g["status"].tolist()
