@@ -65,6 +65,10 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, int iters) {
         if (MODE == 16) asm volatile(RD IND32 W0 ::: CLOB);
         if (MODE == 17) asm volatile(IND32 ST W0 ::: CLOB);
         if (MODE == 18) asm volatile(IND32 "s_nop 7\n\ts_nop 7\n\t" ::: CLOB);
+        if (MODE == 20) asm volatile(IND32 STP ::: CLOB);
+        if (MODE == 21) asm volatile(IND16 ST IND16 ST ::: CLOB);
+        if (MODE == 22) asm volatile(IND16 STP IND16 STP ::: CLOB);
+        if (MODE == 23) asm volatile(IND32 "s_mov_b64 exec, s[20:21]\n\tds_write2_b64 v60, v[10:11], v[12:13] offset0:0 offset1:1\n\ts_mov_b64 exec, -1\n\t" ::: CLOB);
         if (MODE == 19) asm volatile(IND16 "v_max_f32 v50, |v10|, v50\n\tv_max_f32 v50, |v11|, v50\n\tv_add_u32 v52, 8, v60\n\tv_mov_b32 v53, v11\n\t"
                                      "v_max_f32 v50, |v12|, v50\n\tv_max_f32 v50, |v13|, v50\n\tv_add_u32 v52, 8, v60\n\tv_mov_b32 v53, v12\n\t"
                                      "v_max_f32 v50, |v14|, v50\n\tv_max_f32 v50, |v15|, v50\n\tv_add_u32 v52, 8, v60\n\tv_mov_b32 v53, v13\n\t"
@@ -124,6 +128,10 @@ int main() {
     run<16>(dout, "ds_read_b64, 32 independent, s_waitcnt lgkmcnt(0)", bc, bn);
     run<9>(dout, "32 independent + EXEC-masked ds_write_b64 (s_mov exec / write / s_mov exec), no wait", bc, bn);
     run<17>(dout, "32 independent + EXEC-masked ds_write_b64 + s_waitcnt lgkmcnt(0)", bc, bn);
+    run<20>(dout, "32 independent + PLAIN ds_write_b64 (all 64 lanes, 8-byte stride: conflict-free), no wait", bc, bn);
+    run<21>(dout, "2 x (16 independent + EXEC-masked ds_write_b64), no wait", bc, bn);
+    run<22>(dout, "2 x (16 independent + plain ds_write_b64), no wait", bc, bn);
+    run<23>(dout, "32 independent + ONE EXEC-masked ds_write2_b64 (two frames in one instruction), no wait", bc, bn);
     run<10>(dout, "32 independent + s_nop 1 + 2 v_mov_b32_dpp row_shr:1", bc, bn);
     run<11>(dout, "8 x the all-biquad recurrence (s_nop 1, 2 DPP, v_pk_fma, 2 v_cndmask): 48 instructions, all dependent", bc, bn);
     return 0;
