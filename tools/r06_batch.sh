@@ -1,5 +1,5 @@
 #!/bin/bash
-# ad hoc batch of the round (run via gpurun): same-box A/B of two latency-layout builds on configs 2 / 2b + the latency layout's parity tests
+# ad hoc batch of the round (run via gpurun): same-box A/B of two library builds on configs 2 / 2b + the latency layout parity tests (LIBS="libA.so libB.so")
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out/r06z
 LIBS="${LIBS:-libpre_w2.so libdspi_mi355x.so}"
 for c in 2 2b; do echo "== config $c"; bash tools/ab_bench.sh "$LIBS" 2 --config $c --no-side-runs; done > gpurun_out/r06z/ab.txt 2>&1
